@@ -1,0 +1,182 @@
+/*
+ * pmk.h -- C ABI of libpmk_hip.so: the MI355X (gfx950) implementation of the per-patch
+ * GP-regression hot path of PatchMixtureKriging.
+ *
+ * The reference (pure Julia) has no FFI; the surface this ABI replaces is the set of Julia
+ * functions that examples/mixGP.jl and examples/IBB1D.jl call.  Each entry point cites the
+ * reference function (file:line relative to the reference tree) whose work it takes over.
+ * The Julia binding (julia/PatchMixtureKriging) and the Python mirror
+ * (patchmixturekriging_amd) both sit on exactly these symbols; INTEGRATION.md shows the
+ * ccall stubs.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions or callbacks cross the boundary
+ *   - every function returns int status: 0 ok, <0 bad argument / runtime failure
+ *     (text via pmk_last_error()), >0 numerical failure
+ *   - points are packed point-major: X[d + D*i]  (the D x N column-major matrix of
+ *     array2matrix, src/misc/utilities.jl:25-36)
+ *   - dense matrices are column-major; all indices are 0-based (Julia wrappers add 1)
+ *   - host pointers unless the name says _dev; the caller owns host buffers, the library
+ *     owns device memory behind the opaque handles
+ *   - fp64 (the reference is Float64-only: src/RKHS/RKHS.jl:4-11, partition.jl:135)
+ *   - one call at a time per context (the reference is single-threaded); calls that return
+ *     host data block until it is there, the staged *_run / *_fit calls only enqueue on the
+ *     context's stream
+ */
+#ifndef PMK_H
+#define PMK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMK_VERSION 100
+
+/* kernel families = the isbits kernel structs of src/misc/declarations.jl:18-45,65-67,75-111 */
+enum {
+    PMK_SPLINE34 = 1,  /* Spline34KernelType(a)                    kernel.jl:299-313 */
+    PMK_SPLINE12 = 2,  /* Spline12KernelType(a)                    kernel.jl:316-330 */
+    PMK_SPLINE32 = 3,  /* Spline32KernelType(a)                    kernel.jl:333-347 */
+    PMK_GAUSSIAN = 4,  /* GaussianKernel1DType(eps_sq)             kernel.jl:350-357 */
+    PMK_RQ       = 5,  /* RationalQuadraticKernelType(a)           kernel.jl:360-366 */
+    PMK_TRQ      = 6,  /* TunableRationalQuadraticKernelType(a,w)  kernel.jl:368-374 */
+    PMK_MODSQEXP = 7,  /* ModulatedSqExpKernelType(eps_sq,nu), D=1 kernel.jl:376-391 */
+    PMK_BB10     = 10, /* BrownianBridge10                         kernel.jl:156-158 */
+    PMK_BB20     = 11, /* BrownianBridge20                         kernel.jl:218-225 */
+    PMK_BB1EPS   = 12, /* BrownianBridge1eps(eps)                  kernel.jl:168-174 */
+    PMK_BB2EPS   = 13  /* BrownianBridge2eps(eps)                  kernel.jl:176-193 */
+};
+#define PMK_FLAG_SEMIINF 1 /* BrownianBridgeSemiInfDomain{base}      kernel.jl:256-263 */
+
+typedef struct pmk_kernel_desc {
+    int32_t family;
+    int32_t flags;
+    double  p[4];
+} pmk_kernel_desc;
+
+typedef struct pmk_ctx   pmk_ctx;    /* device + stream + workspaces */
+typedef struct pmk_bsp   pmk_bsp;    /* host BSP tree (root of setuppartition) */
+typedef struct pmk_model pmk_model;  /* fitted MixtureGPType on the device */
+typedef struct pmk_query pmk_query;  /* a resident batch of query points + its work items */
+
+int         pmk_version(void);
+const char *pmk_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------- */
+int  pmk_ctx_create(int device, pmk_ctx **out);
+/* launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL -> context's own */
+int  pmk_ctx_set_stream(pmk_ctx *ctx, void *hip_stream);
+int  pmk_ctx_synchronize(pmk_ctx *ctx);
+void pmk_ctx_destroy(pmk_ctx *ctx);
+/* elapsed ms of the most recent staged call's named stage ("kernel_matrix", "cholesky",
+ * "solve", "plan", "items", "mix"); enabled by pmk_ctx_enable_timers(ctx, 1) */
+int  pmk_ctx_enable_timers(pmk_ctx *ctx, int on);
+int  pmk_ctx_timer_ms(pmk_ctx *ctx, const char *stage, double *ms);
+
+/* ---- BSP: host, exact (integer outputs are part of the parity contract) --------------- */
+/* setuppartition(X, levels)  src/patchwork/partition.jl:106-129 (+ gethyperplane :86-100,
+ * splitpoints :64-83, createchildren :166-217, labelleafnodes :131-159).
+ * sign_mode +1: v = +z/|z| ; -1: v = -sign(z1) z/|z|  (SVD sign convention) */
+int     pmk_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, pmk_bsp **out);
+/* rebuild a tree from its pre-order hyperplanes (for shipping a tree between processes) */
+int     pmk_bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, pmk_bsp **out);
+void    pmk_bsp_destroy(pmk_bsp *bsp);
+int     pmk_bsp_dim(const pmk_bsp *bsp);
+int     pmk_bsp_levels(const pmk_bsp *bsp);
+int64_t pmk_bsp_num_leaves(const pmk_bsp *bsp);
+int64_t pmk_bsp_num_points(const pmk_bsp *bsp);
+/* fetchhyperplanes(root)  src/RKHS/mixtureGP.jl:322-334 : pre-order; hp_v is D x (P-1).
+ * leaf_offsets[P+1], leaf_inds[N]: X_parts_inds of setuppartition (ascending per leaf).
+ * Any pointer may be NULL. */
+int     pmk_bsp_arrays(const pmk_bsp *bsp, double *hp_v, double *hp_c,
+                       int64_t *leaf_offsets, int64_t *leaf_inds);
+/* organizetrainingsets(root, levels, X0, eps)  partition.jl:301-357 (+ :269-298).
+ * offsets[P+1] always written; inds[offsets[P]] = X_set_inds grouped by region;
+ * list_offsets[N+1] + lists = regions_list_set.  inds/list_offsets/lists may be NULL
+ * (call once with NULLs to size the buffers). */
+int     pmk_bsp_assign(const pmk_bsp *bsp, int64_t N, const double *X, double eps,
+                       int64_t *offsets, int64_t *inds, int64_t *list_offsets, int64_t *lists);
+/* findpartition(x, root, levels)  partition.jl:248-262 ; returns the leaf or <0 */
+int64_t pmk_bsp_findpartition(const pmk_bsp *bsp, const double *x);
+/* findneighbourpartitions(p, radius, root, levels, hps, home; delta)  mixtureGP.jl:339-405.
+ * returns the number kept (or <0); region_inds[<=P-1]; ts[P-1], zs[D x (P-1)], keep[P-1]
+ * may be NULL. */
+int64_t pmk_bsp_neighbours(const pmk_bsp *bsp, const double *p, double radius, double delta,
+                           int64_t home, int64_t *region_inds, double *ts, double *zs, uint8_t *keep);
+
+/* ---- kernel matrix (device compute, host in/out) -------------------------------------- */
+/* constructkernelmatrix(X, theta)  src/RKHS/RKHS.jl:4-34  (Z == NULL: n x n, exactly symmetric)
+ * constructkernelmatrix(X, Z, theta)  RKHS.jl:95-110      (Z != NULL: n x m) */
+int pmk_kernel_matrix(pmk_ctx *ctx, const pmk_kernel_desc *th, int D,
+                      int64_t n, const double *X, int64_t m, const double *Z,
+                      double *K, int64_t ldk);
+
+/* ---- fit ------------------------------------------------------------------------------ */
+/* MixtureGPType(X_set, hps) + upload: src/RKHS/mixtureGP.jl:54-66.  P patches, patch r has
+ * n[r] points X[r] (D x n[r]) and targets y[r].  Inputs become device-resident. */
+int  pmk_model_create(pmk_ctx *ctx, int D, int64_t P, const int64_t *n,
+                      const double *const *X, const double *const *y, pmk_model **out);
+/* fitmixtureGP!(eta, y_parts, theta, sigma2)  mixtureGP.jl:70-118 on the resident inputs:
+ * per patch K (RKHS.jl:13-34), U = K + sigma2 I, L = chol(U), c = U^-1 y (one Cholesky
+ * serves both; the reference's separate LU of :106 is not repeated).  Enqueues only. */
+int  pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2);
+/* blocks; info[P]: 0 ok, k>0 leading minor k not positive definite (PosDefException(k)) */
+int  pmk_model_info(pmk_model *m, int32_t *info);
+/* replace the resident targets (same sizes) */
+int  pmk_model_set_targets(pmk_model *m, const double *const *y);
+enum { PMK_GET_C = 0, PMK_GET_L = 1, PMK_GET_K = 2, PMK_GET_LINV_DIAG = 3 };
+/* pull c_set[r] (n), L_set[r] (n x n lower, strict upper zero), U_set[r] (n x n, K without
+ * noise, rebuilt on demand), or the inverted 128x128 diagonal blocks (ceil(n/128) blocks,
+ * 128 x 128 each, for tests) */
+int  pmk_model_get(pmk_model *m, int64_t patch, int what, double *out, int64_t ld);
+int64_t pmk_model_num_patches(const pmk_model *m);
+void pmk_model_destroy(pmk_model *m);
+/* one-shot convenience = create + fit + info + c_out (rows 13 and 17 of the scope table;
+ * fitRKHS! src/RKHS/RKHS.jl:182-217 is the P == 1 case).  c_out[r] may be NULL. */
+int  pmk_fit_batched(pmk_ctx *ctx, const pmk_kernel_desc *th, double sigma2, int D, int64_t P,
+                     const int64_t *n, const double *const *X, const double *const *y,
+                     pmk_model **out, double *const *c_out, int32_t *info);
+
+/* ---- predict -------------------------------------------------------------------------- */
+/* attach the tree; this model holds the global leaves [leaf_base, leaf_base + P) */
+int  pmk_model_set_bsp(pmk_model *m, const pmk_bsp *bsp, int64_t leaf_base);
+/* upload Nq query points */
+int  pmk_query_create(pmk_model *m, int64_t Nq, const double *Xq, pmk_query **out);
+/* stage 1: home leaf (partition.jl:248-262) + neighbour items (mixtureGP.jl:339-405) for
+ * every query, items sorted by region (stable).  Blocks (sizes come back to the host). */
+int  pmk_query_plan(pmk_query *q, double radius, double delta);
+/* number of (query, region) items in total and in this model's regions */
+int  pmk_query_counts(pmk_query *q, int64_t *total_items, int64_t *first_owned, int64_t *num_owned);
+/* region_offsets[P_global+1] of the sorted item list (host copy) */
+int  pmk_query_region_offsets(pmk_query *q, int64_t *region_offsets);
+/* stage 2: queryinner! (mixtureGP.jl:296-316) for every owned item: u = kq.c,
+ * v = clamp(k(x,x) - |L^-1 kq|^2, 1e-12, inf).  Enqueues only. */
+int  pmk_query_items(pmk_query *q, const pmk_kernel_desc *th);
+/* device pointers of the per-item results in sorted order (length total_items each); a
+ * multi-GPU caller all-gathers the owned segments into them between stage 2 and 3 */
+int  pmk_query_item_buffers(pmk_query *q, void **u_dev, void **v_dev);
+/* stage 3: mixture weights and blend (mixtureGP.jl:224-272) for queries [q0, q1).  Enqueues. */
+int  pmk_query_mix(pmk_query *q, const pmk_kernel_desc *weight_th, int64_t q0, int64_t q1);
+/* blocks; Yq, Vq [Nq] (either may be NULL) */
+int  pmk_query_fetch(pmk_query *q, double *Yq, double *Vq);
+/* debug_vars of MixtureGPDebugType (mixtureGP.jl:5-35): home[Nq], item_offsets[Nq+1],
+ * then per item in reference order (neighbours in hyperplane order, home last):
+ * item_region, item_t (0 for home), item_w (unnormalised), item_u, item_v.  NULLs allowed. */
+int  pmk_query_debug(pmk_query *q, int64_t *home, int64_t *item_offsets, int64_t *item_region,
+                     double *item_t, double *item_w, double *item_u, double *item_v);
+void pmk_query_destroy(pmk_query *q);
+/* one-shot querymixtureGP!(Yq,Vq,Xq,eta,root,levels,radius,delta,theta,sigma2,weight_theta,..)
+ * src/RKHS/mixtureGP.jl:159-294 for a model that holds every leaf */
+int  pmk_predict_mixture(pmk_model *m, const pmk_kernel_desc *th, const pmk_kernel_desc *weight_th,
+                         int64_t Nq, const double *Xq, double radius, double delta,
+                         double *Yq, double *Vq);
+/* query!(Yq, Xq, eta)  src/RKHS/RKHS.jl:220-247 : mean only, Yq = K(Xq, X) c */
+int  pmk_query_mean(pmk_ctx *ctx, const pmk_kernel_desc *th, int D, int64_t n, const double *X,
+                    const double *c, int64_t Nq, const double *Xq, double *Yq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

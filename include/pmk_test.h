@@ -1,0 +1,29 @@
+/*
+ * pmk_test.h -- self-test entry points of libpmk_hip.so (used by tests/ only).
+ * They exercise the fp64 MFMA tile routines on caller-supplied data so the fragment layout
+ * (cdna_hip_programming.md section 3: v_mfma_f64_16x16x4_f64 does NOT use the f32 C/D map)
+ * is checked with asymmetric integer data on the real device.
+ */
+#ifndef PMK_TEST_H
+#define PMK_TEST_H
+
+#include <stdint.h>
+
+#include "pmk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* C[I][J] (128 x 32, J contiguous: C[J + 32*I]) = sum_k MI[I + 128 k] MJ[J + 32 k],
+ * k < K (K a multiple of 16), through gemm_nt<4,1,4> of one wave.  Host buffers. */
+int pmk_selftest_gemm(pmk_ctx *ctx, int K, const double *MI, const double *MJ, double *C);
+/* T (128 x 32, T[J + 32*I]) <- Linv (128 x 128 column-major, lower) * T through tri_solve_inplace */
+int pmk_selftest_trisolve(pmk_ctx *ctx, const double *Linv, const double *T_in, double *T_out);
+/* sustained fp64 MFMA rate of the device in TFLOP/s (register-resident loop, all CUs) */
+int pmk_selftest_mfma_peak(pmk_ctx *ctx, double *tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,723 @@
+// C ABI of libpmk_hip.so (declared in include/pmk.h): contexts, models, queries.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "pmk_internal.h"
+
+namespace pmk {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t);
+int bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, BspArrays &t);
+int64_t bsp_find(const BspArrays &t, const double *x);
+int bsp_assign(const BspArrays &t, int64_t N, const double *X, double eps, int64_t *offsets, int64_t *inds,
+               int64_t *list_offsets, int64_t *lists);
+int64_t bsp_neighbours(const BspArrays &t, const double *p, double radius, double delta, int64_t home,
+                       int64_t *region_inds, double *ts, double *zs, uint8_t *keep);
+
+static bool kernel_ok(const pmk_kernel_desc *th)
+{
+    if (!th) return false;
+    switch (th->family) {
+    case PMK_SPLINE34: case PMK_SPLINE12: case PMK_SPLINE32: case PMK_GAUSSIAN: case PMK_RQ: case PMK_TRQ:
+    case PMK_MODSQEXP: case PMK_BB10: case PMK_BB20: case PMK_BB1EPS: case PMK_BB2EPS:
+        return true;
+    default:
+        return false;
+    }
+}
+
+template <typename T>
+static int dev_alloc(T **p, int64_t count)
+{
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    PMK_HIP(hipMalloc((void **)p, sizeof(T) * (size_t)count));
+    return 0;
+}
+
+template <typename T>
+static void dev_free(T *&p)
+{
+    if (p) (void)hipFree((void *)p);
+    p = nullptr;
+}
+
+// point-major host points (D x n) -> SoA rows of length ld, zero padded
+static void pack_soa(int D, int64_t n, int64_t ld, const double *X, double *out)
+{
+    for (int d = 0; d < D; ++d) {
+        double *row = out + (int64_t)d * ld;
+        for (int64_t i = 0; i < n; ++i) row[i] = X[i * D + d];
+        for (int64_t i = n; i < ld; ++i) row[i] = 0.0;
+    }
+}
+
+}  // namespace pmk
+
+using namespace pmk;
+
+void pmk_ctx::tic(const char *name)
+{
+    if (!timers) return;
+    for (auto &t : tm)
+        if (t.name == name) { (void)hipEventRecord(t.a, stream); t.valid = false; return; }
+    Timer t;
+    t.name = name;
+    (void)hipEventCreate(&t.a);
+    (void)hipEventCreate(&t.b);
+    t.valid = false;
+    (void)hipEventRecord(t.a, stream);
+    tm.push_back(t);
+}
+
+void pmk_ctx::toc(const char *name)
+{
+    if (!timers) return;
+    for (auto &t : tm)
+        if (t.name == name) { (void)hipEventRecord(t.b, stream); t.valid = true; return; }
+}
+
+extern "C" {
+
+int pmk_version(void) { return PMK_VERSION; }
+const char *pmk_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------ context
+int pmk_ctx_create(int device, pmk_ctx **out)
+{
+    if (!out) { set_error("pmk_ctx_create: out is NULL"); return -2; }
+    *out = nullptr;
+    int ndev = 0;
+    PMK_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) { set_error("pmk_ctx_create: device %d of %d", device, ndev); return -1; }
+    PMK_HIP(hipSetDevice(device));
+    pmk_ctx *c = new (std::nothrow) pmk_ctx();
+    if (!c) { set_error("out of memory"); return -100; }
+    c->device = device;
+    PMK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+int pmk_ctx_set_stream(pmk_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) { set_error("pmk_ctx_set_stream: ctx is NULL"); return -1; }
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return 0;
+}
+
+int pmk_ctx_synchronize(pmk_ctx *ctx)
+{
+    if (!ctx) { set_error("pmk_ctx_synchronize: ctx is NULL"); return -1; }
+    PMK_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+void pmk_ctx_destroy(pmk_ctx *ctx)
+{
+    if (!ctx) return;
+    for (auto &t : ctx->tm) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int pmk_ctx_enable_timers(pmk_ctx *ctx, int on)
+{
+    if (!ctx) { set_error("ctx is NULL"); return -1; }
+    ctx->timers = on != 0;
+    return 0;
+}
+
+int pmk_ctx_timer_ms(pmk_ctx *ctx, const char *stage, double *ms)
+{
+    if (!ctx || !stage || !ms) { set_error("pmk_ctx_timer_ms: NULL argument"); return -1; }
+    for (auto &t : ctx->tm)
+        if (t.name == stage && t.valid) {
+            PMK_HIP(hipEventSynchronize(t.b));
+            float f = 0;
+            PMK_HIP(hipEventElapsedTime(&f, t.a, t.b));
+            *ms = f;
+            return 0;
+        }
+    set_error("no timing recorded for stage '%s'", stage);
+    return -2;
+}
+
+// ------------------------------------------------------------------------------------------ BSP
+int pmk_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, pmk_bsp **out)
+{
+    if (!out) { set_error("pmk_bsp_build: out is NULL"); return -6; }
+    *out = nullptr;
+    if (D < 1 || D > MAX_D) { set_error("pmk_bsp_build: D=%d outside 1..%d", D, MAX_D); return -1; }
+    if (N < 1 || !X) { set_error("pmk_bsp_build: empty point set"); return -2; }
+    if (levels < 2 || levels > 31) { set_error("pmk_bsp_build: levels=%d must be in 2..31", levels); return -4; }
+    if ((N >> (levels - 1)) < 1) { set_error("pmk_bsp_build: N=%lld < 2^(levels-1)", (long long)N); return -4; }
+    pmk_bsp *b = new (std::nothrow) pmk_bsp();
+    if (!b) { set_error("out of memory"); return -100; }
+    int rc = bsp_build(D, N, X, levels, sign_mode, b->t);
+    if (rc) { delete b; return rc; }
+    *out = b;
+    return 0;
+}
+
+int pmk_bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, pmk_bsp **out)
+{
+    if (!out || !hp_v || !hp_c) { set_error("pmk_bsp_from_hyperplanes: NULL argument"); return -1; }
+    *out = nullptr;
+    if (D < 1 || D > MAX_D || levels < 2 || levels > 31) { set_error("pmk_bsp_from_hyperplanes: bad D/levels"); return -1; }
+    pmk_bsp *b = new (std::nothrow) pmk_bsp();
+    if (!b) { set_error("out of memory"); return -100; }
+    bsp_from_hyperplanes(D, levels, hp_v, hp_c, b->t);
+    *out = b;
+    return 0;
+}
+
+void pmk_bsp_destroy(pmk_bsp *bsp) { delete bsp; }
+int pmk_bsp_dim(const pmk_bsp *bsp) { return bsp ? bsp->t.D : -1; }
+int pmk_bsp_levels(const pmk_bsp *bsp) { return bsp ? bsp->t.levels : -1; }
+int64_t pmk_bsp_num_leaves(const pmk_bsp *bsp) { return bsp ? bsp->t.P : -1; }
+int64_t pmk_bsp_num_points(const pmk_bsp *bsp) { return bsp ? bsp->t.N : -1; }
+
+int pmk_bsp_arrays(const pmk_bsp *bsp, double *hp_v, double *hp_c, int64_t *leaf_offsets, int64_t *leaf_inds)
+{
+    if (!bsp) { set_error("pmk_bsp_arrays: bsp is NULL"); return -1; }
+    const BspArrays &t = bsp->t;
+    for (int64_t k = 0; k < t.P - 1; ++k) {
+        const int64_t h = t.pre[(size_t)k];
+        if (hp_v) for (int d = 0; d < t.D; ++d) hp_v[k * t.D + d] = t.v[(size_t)(h * t.D + d)];
+        if (hp_c) hp_c[k] = t.c[(size_t)h];
+    }
+    if (leaf_offsets) std::memcpy(leaf_offsets, t.leaf_off.data(), sizeof(int64_t) * (size_t)(t.P + 1));
+    if (leaf_inds && !t.leaf_inds.empty()) std::memcpy(leaf_inds, t.leaf_inds.data(), sizeof(int64_t) * t.leaf_inds.size());
+    return 0;
+}
+
+int pmk_bsp_assign(const pmk_bsp *bsp, int64_t N, const double *X, double eps, int64_t *offsets, int64_t *inds,
+                   int64_t *list_offsets, int64_t *lists)
+{
+    if (!bsp || !offsets || (N > 0 && !X)) { set_error("pmk_bsp_assign: NULL argument"); return -1; }
+    return bsp_assign(bsp->t, N, X, eps, offsets, inds, list_offsets, lists);
+}
+
+int64_t pmk_bsp_findpartition(const pmk_bsp *bsp, const double *x)
+{
+    if (!bsp || !x) { set_error("pmk_bsp_findpartition: NULL argument"); return -1; }
+    return bsp_find(bsp->t, x);
+}
+
+int64_t pmk_bsp_neighbours(const pmk_bsp *bsp, const double *p, double radius, double delta, int64_t home,
+                           int64_t *region_inds, double *ts, double *zs, uint8_t *keep)
+{
+    if (!bsp || !p || !region_inds) { set_error("pmk_bsp_neighbours: NULL argument"); return -1; }
+    return bsp_neighbours(bsp->t, p, radius, delta, home, region_inds, ts, zs, keep);
+}
+
+// ------------------------------------------------------------------------------------------ kernel matrix
+int pmk_kernel_matrix(pmk_ctx *ctx, const pmk_kernel_desc *th, int D, int64_t n, const double *X, int64_t m,
+                      const double *Z, double *K, int64_t ldk)
+{
+    if (!ctx) { set_error("pmk_kernel_matrix: ctx is NULL"); return -1; }
+    if (!kernel_ok(th)) { set_error("pmk_kernel_matrix: unknown kernel family"); return -2; }
+    if (D < 1 || D > MAX_D) { set_error("pmk_kernel_matrix: D=%d outside 1..%d", D, MAX_D); return -3; }
+    if (n < 1 || !X || !K) { set_error("pmk_kernel_matrix: empty input"); return -4; }
+    const bool sym = (Z == nullptr);
+    const int64_t mc = sym ? n : m;
+    if (mc < 1 || ldk < n) { set_error("pmk_kernel_matrix: bad m/ldk"); return -6; }
+    PMK_HIP(hipSetDevice(ctx->device));
+    std::vector<double> hx((size_t)(n * D)), hz;
+    pack_soa(D, n, n, X, hx.data());
+    double *dx = nullptr, *dz = nullptr, *dK = nullptr;
+    if (dev_alloc(&dx, n * D)) return -100;
+    PMK_HIP(hipMemcpyAsync(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!sym) {
+        hz.resize((size_t)(mc * D));
+        pack_soa(D, mc, mc, Z, hz.data());
+        if (dev_alloc(&dz, mc * D)) return -100;
+        PMK_HIP(hipMemcpyAsync(dz, hz.data(), sizeof(double) * hz.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (dev_alloc(&dK, n * mc)) return -100;
+    int rc = launch_kernel_matrix_dense(*th, D, n, dx, n, mc, sym ? dx : dz, sym ? n : mc, dK, n, sym, ctx->stream);
+    if (!rc) {
+        PMK_HIP(hipMemcpy2DAsync(K, sizeof(double) * ldk, dK, sizeof(double) * n, sizeof(double) * n, (size_t)mc,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+        PMK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    dev_free(dx); dev_free(dz); dev_free(dK);
+    return rc;
+}
+
+int pmk_query_mean(pmk_ctx *ctx, const pmk_kernel_desc *th, int D, int64_t n, const double *X, const double *c,
+                   int64_t Nq, const double *Xq, double *Yq)
+{
+    if (!ctx) { set_error("pmk_query_mean: ctx is NULL"); return -1; }
+    if (!kernel_ok(th)) { set_error("pmk_query_mean: unknown kernel family"); return -2; }
+    if (D < 1 || D > MAX_D) { set_error("pmk_query_mean: D=%d outside 1..%d", D, MAX_D); return -3; }
+    if (n < 1 || !X || !c) { set_error("pmk_query_mean: empty model"); return -4; }
+    if (Nq < 1 || !Xq || !Yq) { set_error("pmk_query_mean: empty query (the reference asserts !isempty(Xq))"); return -7; }
+    PMK_HIP(hipSetDevice(ctx->device));
+    std::vector<double> hx((size_t)(n * D));
+    pack_soa(D, n, n, X, hx.data());
+    double *dx = nullptr, *dc = nullptr, *dq = nullptr, *dy = nullptr;
+    if (dev_alloc(&dx, n * D) || dev_alloc(&dc, n) || dev_alloc(&dq, Nq * D) || dev_alloc(&dy, Nq)) return -100;
+    PMK_HIP(hipMemcpyAsync(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, ctx->stream));
+    PMK_HIP(hipMemcpyAsync(dc, c, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    PMK_HIP(hipMemcpyAsync(dq, Xq, sizeof(double) * Nq * D, hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_query_mean(*th, D, n, dx, n, dc, Nq, dq, dy, ctx->stream);
+    if (!rc) {
+        PMK_HIP(hipMemcpyAsync(Yq, dy, sizeof(double) * Nq, hipMemcpyDeviceToHost, ctx->stream));
+        PMK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    dev_free(dx); dev_free(dc); dev_free(dq); dev_free(dy);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------ model
+void pmk_model_destroy(pmk_model *m)
+{
+    if (!m) return;
+    dev_free(m->d_desc); dev_free(m->d_x); dev_free(m->d_y); dev_free(m->d_z); dev_free(m->d_c);
+    dev_free(m->d_a); dev_free(m->d_inv); dev_free(m->d_info); dev_free(m->d_hv); dev_free(m->d_hc);
+    dev_free(m->d_pre); dev_free(m->d_strip);
+    delete m;
+}
+
+static int upload_targets(pmk_model *m, const double *const *y)
+{
+    std::vector<double> hy((size_t)m->tot_y, 0.0);
+    for (int64_t r = 0; r < m->P; ++r) {
+        if (!y[r]) { set_error("targets of patch %lld are NULL", (long long)r); return -6; }
+        std::memcpy(hy.data() + m->desc[(size_t)r].yoff, y[r], sizeof(double) * (size_t)m->desc[(size_t)r].n);
+    }
+    PMK_HIP(hipMemcpy(m->d_y, hy.data(), sizeof(double) * hy.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int pmk_model_create(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const double *const *X,
+                     const double *const *y, pmk_model **out)
+{
+    if (!out) { set_error("pmk_model_create: out is NULL"); return -7; }
+    *out = nullptr;
+    if (!ctx) { set_error("pmk_model_create: ctx is NULL"); return -1; }
+    if (D < 1 || D > MAX_D) { set_error("pmk_model_create: D=%d outside 1..%d", D, MAX_D); return -2; }
+    if (P < 1 || !n || !X || !y) { set_error("pmk_model_create: no patches"); return -3; }
+    PMK_HIP(hipSetDevice(ctx->device));
+    pmk_model *m = new (std::nothrow) pmk_model();
+    if (!m) { set_error("out of memory"); return -100; }
+    m->ctx = ctx; m->D = D; m->P = P;
+    m->desc.resize((size_t)P);
+    int64_t a = 0, xo = 0, yo = 0, io = 0;
+    for (int64_t r = 0; r < P; ++r) {
+        if (n[r] < 1 || n[r] > (1 << 24) || !X[r]) {
+            set_error("pmk_model_create: patch %lld has n=%lld (the reference asserts a non-empty patch)", (long long)r,
+                      (long long)n[r]);
+            delete m;
+            return -4;
+        }
+        PatchDesc &d = m->desc[(size_t)r];
+        d.n = (int32_t)n[r];
+        d.nt = (int32_t)((n[r] + TILE - 1) / TILE);
+        d.ld = d.nt * TILE;
+        d.pad_ = 0;
+        d.aoff = a; d.xoff = xo; d.yoff = yo; d.ioff = io;
+        a += (int64_t)d.ld * d.ld;
+        xo += (int64_t)d.ld * D;
+        yo += d.ld;
+        io += (int64_t)d.nt * TILE * TILE;
+        m->max_nt = std::max(m->max_nt, (int)d.nt);
+    }
+    m->tot_a = a; m->tot_x = xo; m->tot_y = yo; m->tot_inv = io;
+    int rc = 0;
+    rc |= dev_alloc(&m->d_desc, P);
+    rc |= dev_alloc(&m->d_x, xo);
+    rc |= dev_alloc(&m->d_y, yo);
+    rc |= dev_alloc(&m->d_z, yo);
+    rc |= dev_alloc(&m->d_c, yo);
+    rc |= dev_alloc(&m->d_a, a);
+    rc |= dev_alloc(&m->d_inv, io);
+    rc |= dev_alloc(&m->d_info, P);
+    if (rc) { pmk_model_destroy(m); return -100; }
+    {
+        std::vector<double> hx((size_t)xo);
+        for (int64_t r = 0; r < P; ++r) {
+            const PatchDesc &d = m->desc[(size_t)r];
+            pack_soa(D, d.n, d.ld, X[r], hx.data() + d.xoff);
+        }
+        if (hipMemcpy(m->d_x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(m->d_desc, m->desc.data(), sizeof(PatchDesc) * (size_t)P, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("pmk_model_create: upload failed");
+            pmk_model_destroy(m);
+            return -100;
+        }
+    }
+    rc = upload_targets(m, y);
+    if (rc) { pmk_model_destroy(m); return rc; }
+    PMK_HIP(hipMemset(m->d_info, 0, sizeof(int32_t) * (size_t)P));
+    *out = m;
+    return 0;
+}
+
+int pmk_model_set_targets(pmk_model *m, const double *const *y)
+{
+    if (!m || !y) { set_error("pmk_model_set_targets: NULL argument"); return -1; }
+    PMK_HIP(hipSetDevice(m->ctx->device));
+    PMK_HIP(hipStreamSynchronize(m->ctx->stream));
+    m->fitted = false;
+    return upload_targets(m, y);
+}
+
+int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)
+{
+    if (!m) { set_error("pmk_model_fit: model is NULL"); return -1; }
+    if (!kernel_ok(th)) { set_error("pmk_model_fit: unknown kernel family"); return -2; }
+    PMK_HIP(hipSetDevice(m->ctx->device));
+    pmk_ctx *c = m->ctx;
+    m->th = *th;
+    m->sigma2 = sigma2;
+    int rc;
+    c->tic("fit");
+    c->tic("kernel_matrix");
+    if ((rc = launch_kernel_matrix_slabs(m, *th, sigma2, c->stream))) return rc;
+    c->toc("kernel_matrix");
+    c->tic("cholesky");
+    if ((rc = launch_cholesky(m, c->stream))) return rc;
+    c->toc("cholesky");
+    c->tic("solve");
+    if ((rc = launch_backsolve(m, c->stream))) return rc;
+    c->toc("solve");
+    c->toc("fit");
+    m->fitted = true;
+    return 0;
+}
+
+int pmk_model_info(pmk_model *m, int32_t *info)
+{
+    if (!m || !info) { set_error("pmk_model_info: NULL argument"); return -1; }
+    PMK_HIP(hipSetDevice(m->ctx->device));
+    PMK_HIP(hipMemcpyAsync(info, m->d_info, sizeof(int32_t) * (size_t)m->P, hipMemcpyDeviceToHost, m->ctx->stream));
+    PMK_HIP(hipStreamSynchronize(m->ctx->stream));
+    int worst = 0;
+    for (int64_t r = 0; r < m->P; ++r) {
+        // a failure inside the identity padding cannot happen; clamp to the patch size for safety
+        if (info[r] > m->desc[(size_t)r].n) info[r] = m->desc[(size_t)r].n;
+        if (info[r] > 0 && !worst) worst = 1;
+    }
+    return worst;
+}
+
+int64_t pmk_model_num_patches(const pmk_model *m) { return m ? m->P : -1; }
+
+int pmk_model_get(pmk_model *m, int64_t patch, int what, double *out, int64_t ld)
+{
+    if (!m || !out) { set_error("pmk_model_get: NULL argument"); return -1; }
+    if (patch < 0 || patch >= m->P) { set_error("pmk_model_get: patch %lld of %lld", (long long)patch, (long long)m->P); return -2; }
+    const PatchDesc &d = m->desc[(size_t)patch];
+    pmk_ctx *c = m->ctx;
+    PMK_HIP(hipSetDevice(c->device));
+    if (what != PMK_GET_K && !m->fitted) { set_error("pmk_model_get: model is not fitted"); return -3; }
+    switch (what) {
+    case PMK_GET_C:
+        PMK_HIP(hipMemcpyAsync(out, m->d_c + d.yoff, sizeof(double) * (size_t)d.n, hipMemcpyDeviceToHost, c->stream));
+        PMK_HIP(hipStreamSynchronize(c->stream));
+        return 0;
+    case PMK_GET_L: {
+        if (ld < d.n) { set_error("pmk_model_get: ld too small"); return -5; }
+        PMK_HIP(hipMemcpy2DAsync(out, sizeof(double) * ld, m->d_a + d.aoff, sizeof(double) * d.ld, sizeof(double) * d.n,
+                                 (size_t)d.n, hipMemcpyDeviceToHost, c->stream));
+        PMK_HIP(hipStreamSynchronize(c->stream));
+        for (int64_t j = 1; j < d.n; ++j)
+            for (int64_t i = 0; i < j; ++i) out[i + j * ld] = 0.0;   // .L of the reference: strict upper = 0
+        return 0;
+    }
+    case PMK_GET_K: {
+        // U_set entry (mixtureGP.jl:99): K without noise, rebuilt on demand from the resident points
+        if (ld < d.n) { set_error("pmk_model_get: ld too small"); return -5; }
+        if (!kernel_ok(&m->th)) { set_error("pmk_model_get: no kernel set (fit first)"); return -3; }
+        double *dK = nullptr;
+        if (dev_alloc(&dK, (int64_t)d.n * d.n)) return -100;
+        int rc = launch_kernel_matrix_dense(m->th, m->D, d.n, m->d_x + d.xoff, d.ld, d.n, m->d_x + d.xoff, d.ld, dK, d.n,
+                                            true, c->stream);
+        if (!rc) {
+            PMK_HIP(hipMemcpy2DAsync(out, sizeof(double) * ld, dK, sizeof(double) * d.n, sizeof(double) * d.n, (size_t)d.n,
+                                     hipMemcpyDeviceToHost, c->stream));
+            PMK_HIP(hipStreamSynchronize(c->stream));
+        }
+        dev_free(dK);
+        return rc;
+    }
+    case PMK_GET_LINV_DIAG:
+        PMK_HIP(hipMemcpyAsync(out, m->d_inv + d.ioff, sizeof(double) * (size_t)d.nt * TILE * TILE, hipMemcpyDeviceToHost,
+                               c->stream));
+        PMK_HIP(hipStreamSynchronize(c->stream));
+        return 0;
+    default:
+        set_error("pmk_model_get: unknown selector %d", what);
+        return -3;
+    }
+}
+
+int pmk_fit_batched(pmk_ctx *ctx, const pmk_kernel_desc *th, double sigma2, int D, int64_t P, const int64_t *n,
+                    const double *const *X, const double *const *y, pmk_model **out, double *const *c_out,
+                    int32_t *info)
+{
+    if (!out) { set_error("pmk_fit_batched: out is NULL"); return -9; }
+    int rc = pmk_model_create(ctx, D, P, n, X, y, out);
+    if (rc) return rc;
+    rc = pmk_model_fit(*out, th, sigma2);
+    if (rc) { pmk_model_destroy(*out); *out = nullptr; return rc; }
+    std::vector<int32_t> tmp((size_t)P);
+    int st = pmk_model_info(*out, info ? info : tmp.data());
+    if (st < 0) return st;
+    if (c_out)
+        for (int64_t r = 0; r < P; ++r)
+            if (c_out[r] && (rc = pmk_model_get(*out, r, PMK_GET_C, c_out[r], 0))) return rc;
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------ predict
+int pmk_model_set_bsp(pmk_model *m, const pmk_bsp *bsp, int64_t leaf_base)
+{
+    if (!m || !bsp) { set_error("pmk_model_set_bsp: NULL argument"); return -1; }
+    const BspArrays &t = bsp->t;
+    if (t.D != m->D) { set_error("pmk_model_set_bsp: tree dimension %d != model dimension %d", t.D, m->D); return -2; }
+    if (leaf_base < 0 || leaf_base + m->P > t.P) {
+        set_error("pmk_model_set_bsp: leaves [%lld, %lld) outside the tree's %lld leaves", (long long)leaf_base,
+                  (long long)(leaf_base + m->P), (long long)t.P);
+        return -3;
+    }
+    PMK_HIP(hipSetDevice(m->ctx->device));
+    dev_free(m->d_hv); dev_free(m->d_hc); dev_free(m->d_pre);
+    if (dev_alloc(&m->d_hv, (t.P - 1) * t.D) || dev_alloc(&m->d_hc, t.P - 1) || dev_alloc(&m->d_pre, t.P - 1)) return -100;
+    std::vector<int32_t> pre32((size_t)(t.P - 1));
+    for (size_t i = 0; i < pre32.size(); ++i) pre32[i] = (int32_t)t.pre[i];
+    if (t.P > 1) {
+        PMK_HIP(hipMemcpy(m->d_hv, t.v.data(), sizeof(double) * t.v.size(), hipMemcpyHostToDevice));
+        PMK_HIP(hipMemcpy(m->d_hc, t.c.data(), sizeof(double) * t.c.size(), hipMemcpyHostToDevice));
+        PMK_HIP(hipMemcpy(m->d_pre, pre32.data(), sizeof(int32_t) * pre32.size(), hipMemcpyHostToDevice));
+    }
+    m->levels = t.levels;
+    m->P_global = t.P;
+    m->leaf_base = leaf_base;
+    return 0;
+}
+
+void pmk_query_destroy(pmk_query *q)
+{
+    if (!q) return;
+    dev_free(q->d_xq); dev_free(q->d_home); dev_free(q->d_cnt); dev_free(q->d_qoff);
+    dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
+    dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_roff);
+    dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w); dev_free(q->d_yq); dev_free(q->d_vq);
+    if (q->d_tmp) (void)hipFree(q->d_tmp);
+    if (q->d_tasks) (void)hipFree(q->d_tasks);
+    delete q;
+}
+
+int pmk_query_create(pmk_model *m, int64_t Nq, const double *Xq, pmk_query **out)
+{
+    if (!out) { set_error("pmk_query_create: out is NULL"); return -4; }
+    *out = nullptr;
+    if (!m) { set_error("pmk_query_create: model is NULL"); return -1; }
+    if (Nq < 0 || Nq > 0x7fffffff || (Nq > 0 && !Xq)) { set_error("pmk_query_create: bad Nq"); return -2; }
+    if (m->P_global == 0) { set_error("pmk_query_create: attach a tree with pmk_model_set_bsp first"); return -1; }
+    PMK_HIP(hipSetDevice(m->ctx->device));
+    pmk_query *q = new (std::nothrow) pmk_query();
+    if (!q) { set_error("out of memory"); return -100; }
+    q->m = m; q->Nq = Nq;
+    int rc = 0;
+    rc |= dev_alloc(&q->d_xq, Nq * m->D);
+    rc |= dev_alloc(&q->d_home, Nq);
+    rc |= dev_alloc(&q->d_cnt, Nq + 1);
+    rc |= dev_alloc(&q->d_qoff, Nq + 1);
+    rc |= dev_alloc(&q->d_roff, m->P_global + 1);
+    rc |= dev_alloc(&q->d_yq, Nq);
+    rc |= dev_alloc(&q->d_vq, Nq);
+    if (rc) { pmk_query_destroy(q); return -100; }
+    if (Nq > 0) PMK_HIP(hipMemcpy(q->d_xq, Xq, sizeof(double) * (size_t)(Nq * m->D), hipMemcpyHostToDevice));
+    *out = q;
+    return 0;
+}
+
+int pmk_query_plan(pmk_query *q, double radius, double delta)
+{
+    if (!q) { set_error("pmk_query_plan: query is NULL"); return -1; }
+    pmk_model *m = q->m;
+    pmk_ctx *c = m->ctx;
+    PMK_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    c->tic("plan");
+    q->planned = false;
+    dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
+    dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w);
+    q->total = 0;
+    q->roff.assign((size_t)(m->P_global + 1), 0);
+    if (q->Nq > 0) {
+        int rc;
+        PMK_HIP(hipMemsetAsync(q->d_cnt, 0, sizeof(int32_t) * (size_t)(q->Nq + 1), s));
+        if ((rc = launch_plan_count(q, radius, delta, s))) return rc;
+        if (exclusive_scan_i32_to_i64(q->d_cnt, q->d_qoff, q->Nq, &q->d_tmp, &q->tmp_bytes, s)) {
+            set_error("pmk_query_plan: prefix scan failed");
+            return -100;
+        }
+        PMK_HIP(hipMemcpyAsync(&q->total, q->d_qoff + q->Nq, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        PMK_HIP(hipStreamSynchronize(s));
+        if (q->total > 0x7fffffff) { set_error("pmk_query_plan: too many work items (%lld)", (long long)q->total); return -5; }
+        rc = 0;
+        rc |= dev_alloc(&q->d_item_region, q->total);
+        rc |= dev_alloc(&q->d_item_t, q->total);
+        rc |= dev_alloc(&q->d_item_query, q->total);
+        rc |= dev_alloc(&q->d_sorted_item, q->total);
+        rc |= dev_alloc(&q->d_item_pos, q->total);
+        rc |= dev_alloc(&q->d_u, q->total);
+        rc |= dev_alloc(&q->d_v, q->total);
+        rc |= dev_alloc(&q->d_w, q->total);
+        if (rc) return -100;
+        if ((rc = launch_plan_fill(q, radius, delta, s))) return rc;
+        if ((rc = launch_sort_items(q, s))) return rc;
+        PMK_HIP(hipMemcpyAsync(q->roff.data(), q->d_roff, sizeof(int64_t) * q->roff.size(), hipMemcpyDeviceToHost, s));
+        PMK_HIP(hipStreamSynchronize(s));
+        if ((rc = build_strip_tasks(q, s))) return rc;
+    }
+    c->toc("plan");
+    q->planned = true;
+    return 0;
+}
+
+int pmk_query_counts(pmk_query *q, int64_t *total_items, int64_t *first_owned, int64_t *num_owned)
+{
+    if (!q || !q->planned) { set_error("pmk_query_counts: query is not planned"); return -1; }
+    const pmk_model *m = q->m;
+    if (total_items) *total_items = q->total;
+    if (first_owned) *first_owned = q->roff[(size_t)m->leaf_base];
+    if (num_owned) *num_owned = q->roff[(size_t)(m->leaf_base + m->P)] - q->roff[(size_t)m->leaf_base];
+    return 0;
+}
+
+int pmk_query_region_offsets(pmk_query *q, int64_t *region_offsets)
+{
+    if (!q || !q->planned || !region_offsets) { set_error("pmk_query_region_offsets: query is not planned"); return -1; }
+    std::memcpy(region_offsets, q->roff.data(), sizeof(int64_t) * q->roff.size());
+    return 0;
+}
+
+int pmk_query_items(pmk_query *q, const pmk_kernel_desc *th)
+{
+    if (!q || !q->planned) { set_error("pmk_query_items: query is not planned"); return -1; }
+    if (!kernel_ok(th)) { set_error("pmk_query_items: unknown kernel family"); return -2; }
+    if (!q->m->fitted) { set_error("pmk_query_items: model is not fitted"); return -1; }
+    pmk_ctx *c = q->m->ctx;
+    PMK_HIP(hipSetDevice(c->device));
+    c->tic("items");
+    int rc = launch_items(q, *th, c->stream);
+    c->toc("items");
+    return rc;
+}
+
+int pmk_query_item_buffers(pmk_query *q, void **u_dev, void **v_dev)
+{
+    if (!q || !q->planned) { set_error("pmk_query_item_buffers: query is not planned"); return -1; }
+    if (u_dev) *u_dev = q->d_u;
+    if (v_dev) *v_dev = q->d_v;
+    return 0;
+}
+
+int pmk_query_mix(pmk_query *q, const pmk_kernel_desc *weight_th, int64_t q0, int64_t q1)
+{
+    if (!q || !q->planned) { set_error("pmk_query_mix: query is not planned"); return -1; }
+    if (!kernel_ok(weight_th) || weight_th->family >= PMK_BB10) {
+        set_error("pmk_query_mix: the blending profile must be a stationary kernel (evalkernel(tau, theta))");
+        return -2;
+    }
+    if (q0 < 0 || q1 > q->Nq || q0 > q1) { set_error("pmk_query_mix: bad query range"); return -3; }
+    pmk_ctx *c = q->m->ctx;
+    PMK_HIP(hipSetDevice(c->device));
+    c->tic("mix");
+    int rc = launch_mix(q, *weight_th, q0, q1, c->stream);
+    c->toc("mix");
+    return rc;
+}
+
+int pmk_query_fetch(pmk_query *q, double *Yq, double *Vq)
+{
+    if (!q) { set_error("pmk_query_fetch: query is NULL"); return -1; }
+    pmk_ctx *c = q->m->ctx;
+    PMK_HIP(hipSetDevice(c->device));
+    if (q->Nq > 0) {
+        if (Yq) PMK_HIP(hipMemcpyAsync(Yq, q->d_yq, sizeof(double) * (size_t)q->Nq, hipMemcpyDeviceToHost, c->stream));
+        if (Vq) PMK_HIP(hipMemcpyAsync(Vq, q->d_vq, sizeof(double) * (size_t)q->Nq, hipMemcpyDeviceToHost, c->stream));
+    }
+    PMK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int pmk_query_debug(pmk_query *q, int64_t *home, int64_t *item_offsets, int64_t *item_region, double *item_t,
+                    double *item_w, double *item_u, double *item_v)
+{
+    if (!q || !q->planned) { set_error("pmk_query_debug: query is not planned"); return -1; }
+    pmk_ctx *c = q->m->ctx;
+    PMK_HIP(hipSetDevice(c->device));
+    PMK_HIP(hipStreamSynchronize(c->stream));
+    const size_t Nq = (size_t)q->Nq, T = (size_t)q->total;
+    if (home && Nq) {
+        std::vector<int32_t> h(Nq);
+        PMK_HIP(hipMemcpy(h.data(), q->d_home, sizeof(int32_t) * Nq, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < Nq; ++i) home[i] = h[i];
+    }
+    if (item_offsets) PMK_HIP(hipMemcpy(item_offsets, q->d_qoff, sizeof(int64_t) * (Nq + 1), hipMemcpyDeviceToHost));
+    if (T == 0) return 0;
+    if (item_region) {
+        std::vector<int32_t> r(T);
+        PMK_HIP(hipMemcpy(r.data(), q->d_item_region, sizeof(int32_t) * T, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < T; ++i) item_region[i] = r[i];
+    }
+    if (item_t) PMK_HIP(hipMemcpy(item_t, q->d_item_t, sizeof(double) * T, hipMemcpyDeviceToHost));
+    if (item_w) PMK_HIP(hipMemcpy(item_w, q->d_w, sizeof(double) * T, hipMemcpyDeviceToHost));
+    if (item_u || item_v) {
+        std::vector<int32_t> pos(T);
+        std::vector<double> tmp(T);
+        PMK_HIP(hipMemcpy(pos.data(), q->d_item_pos, sizeof(int32_t) * T, hipMemcpyDeviceToHost));
+        if (item_u) {
+            PMK_HIP(hipMemcpy(tmp.data(), q->d_u, sizeof(double) * T, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < T; ++i) item_u[i] = tmp[(size_t)pos[i]];
+        }
+        if (item_v) {
+            PMK_HIP(hipMemcpy(tmp.data(), q->d_v, sizeof(double) * T, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < T; ++i) item_v[i] = tmp[(size_t)pos[i]];
+        }
+    }
+    return 0;
+}
+
+int pmk_predict_mixture(pmk_model *m, const pmk_kernel_desc *th, const pmk_kernel_desc *weight_th, int64_t Nq,
+                        const double *Xq, double radius, double delta, double *Yq, double *Vq)
+{
+    if (!m) { set_error("pmk_predict_mixture: model is NULL"); return -1; }
+    if (m->P_global != m->P || m->leaf_base != 0) {
+        set_error("pmk_predict_mixture: the model holds %lld of %lld leaves; use the staged pmk_query_* calls",
+                  (long long)m->P, (long long)m->P_global);
+        return -1;
+    }
+    pmk_query *q = nullptr;
+    int rc = pmk_query_create(m, Nq, Xq, &q);
+    if (rc) return rc;
+    if (!(rc = pmk_query_plan(q, radius, delta)) && !(rc = pmk_query_items(q, th)) &&
+        !(rc = pmk_query_mix(q, weight_th, 0, Nq)))
+        rc = pmk_query_fetch(q, Yq, Vq);
+    pmk_query_destroy(q);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+// Internal declarations shared by the host side and the HIP kernels of libpmk_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pmk.h"
+
+namespace pmk {
+
+constexpr int TILE = 128;       // factorisation tile edge; slabs are padded to a multiple of it
+constexpr int MAX_D = 4;        // input dimension limit (the reference's examples use 1, 2 and 3)
+constexpr int TQ = 128;         // query columns per prediction strip (4 waves x 32)
+
+void set_error(const char *fmt, ...);
+
+#define PMK_HIP(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            pmk::set_error("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__,              \
+                           hipGetErrorString(e__));                                          \
+            return -100;                                                                     \
+        }                                                                                    \
+    } while (0)
+
+// Per-patch geometry, resident on the device (one entry per patch).
+struct PatchDesc {
+    int32_t n;        // points in the patch
+    int32_t nt;       // ceil(n / TILE)
+    int32_t ld;       // nt * TILE : leading dimension of the slab, padded with identity
+    int32_t pad_;
+    int64_t aoff;     // element offset of the ld x ld slab (K, then L in place)
+    int64_t xoff;     // element offset of the SoA coordinates: x[d][ld]
+    int64_t yoff;     // element offset into y / z / c (ld each)
+    int64_t ioff;     // element offset of the inverted diagonal blocks: nt x (TILE x TILE)
+};
+
+// A BSP tree in heap order (root 0, children 2i+1 / 2i+2); leaves numbered left to right.
+struct BspArrays {
+    int D = 0, levels = 0;
+    int64_t P = 0, N = 0;
+    std::vector<double> v;          // (P-1) x D heap order
+    std::vector<double> c;          // P-1
+    std::vector<int64_t> pre;       // pre-order rank -> heap index
+    std::vector<int64_t> leaf_off;  // P+1
+    std::vector<int64_t> leaf_inds; // N
+};
+
+}  // namespace pmk
+
+struct pmk_bsp {
+    pmk::BspArrays t;
+};
+
+struct pmk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool timers = false;
+    struct Timer { std::string name; hipEvent_t a, b; bool valid; };
+    std::vector<Timer> tm;
+    void tic(const char *name);
+    void toc(const char *name);
+};
+
+struct pmk_model {
+    pmk_ctx *ctx = nullptr;
+    int D = 0;
+    int64_t P = 0;
+    int max_nt = 0;
+    std::vector<pmk::PatchDesc> desc;   // host copy
+    pmk::PatchDesc *d_desc = nullptr;
+    double *d_x = nullptr;              // SoA coordinates
+    double *d_y = nullptr;              // targets (padded with 0)
+    double *d_z = nullptr;              // L^-1 y
+    double *d_c = nullptr;              // weights
+    double *d_a = nullptr;              // slabs
+    double *d_inv = nullptr;            // inverted diagonal blocks
+    int32_t *d_info = nullptr;          // per patch
+    int64_t tot_a = 0, tot_x = 0, tot_y = 0, tot_inv = 0;
+    bool fitted = false;
+    pmk_kernel_desc th{};
+    double sigma2 = 0;
+    // BSP for prediction (heap order on device)
+    int levels = 0;
+    int64_t P_global = 0, leaf_base = 0;
+    double *d_hv = nullptr, *d_hc = nullptr;   // heap order
+    int32_t *d_pre = nullptr;                  // pre-order -> heap
+    // prediction strip workspace
+    double *d_strip = nullptr;
+    int64_t strip_slots = 0;
+};
+
+struct pmk_query {
+    pmk_model *m = nullptr;
+    int64_t Nq = 0;
+    double *d_xq = nullptr;         // point-major D x Nq
+    int32_t *d_home = nullptr;      // Nq
+    int32_t *d_cnt = nullptr;       // Nq : items per query (neighbours + 1)
+    int64_t *d_qoff = nullptr;      // Nq+1
+    int64_t total = 0;
+    int32_t *d_item_region = nullptr;   // total, reference order
+    double *d_item_t = nullptr;         // total (0 for home)
+    int32_t *d_item_query = nullptr;    // total
+    int32_t *d_sorted_item = nullptr;   // total: sorted position -> item
+    int32_t *d_item_pos = nullptr;      // total: item -> sorted position
+    int64_t *d_roff = nullptr;          // P_global+1
+    std::vector<int64_t> roff;          // host copy
+    double *d_u = nullptr, *d_v = nullptr;   // sorted order
+    double *d_w = nullptr;                   // reference order (unnormalised), debug
+    double *d_yq = nullptr, *d_vq = nullptr; // Nq
+    void *d_tmp = nullptr; size_t tmp_bytes = 0;
+    void *d_tasks = nullptr; int64_t ntasks = 0, strip_grid = 0;   // prediction strip tasks (owned regions)
+    bool planned = false;
+};
+
+namespace pmk {
+
+// ---- launchers implemented in the .hip files (all enqueue on `s`) ----
+int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s);
+int launch_kernel_matrix_dense(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
+                               int64_t mcols, const double *d_zs, int64_t ldz, double *d_K, int64_t ldk,
+                               bool symmetric, hipStream_t s);
+int launch_cholesky(pmk_model *m, hipStream_t s);
+int launch_backsolve(pmk_model *m, hipStream_t s);
+int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s);
+int launch_plan_fill(pmk_query *q, double radius, double delta, hipStream_t s);
+int launch_sort_items(pmk_query *q, hipStream_t s);
+int build_strip_tasks(pmk_query *q, hipStream_t s);
+int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s);
+int launch_mix(pmk_query *q, const pmk_kernel_desc &wth, int64_t q0, int64_t q1, hipStream_t s);
+int launch_query_mean(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
+                      const double *d_c, int64_t nq, const double *d_xq, double *d_yq, hipStream_t s);
+int64_t exclusive_scan_i32_to_i64(const int32_t *d_in, int64_t *d_out, int64_t n, void **tmp, size_t *tmp_bytes,
+                                  hipStream_t s);
+
+}  // namespace pmk

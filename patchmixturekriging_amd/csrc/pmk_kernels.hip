@@ -1,0 +1,369 @@
+// K1 (kernel-matrix build), K5 (query-side BSP search + item list), K6 (mixture) and small helpers.
+#include <hipcub/hipcub.hpp>
+
+#include "pmk_device.h"
+
+namespace pmk {
+
+// =============================================================================================
+// K1: batched kernel-matrix build into the factorisation slabs.
+// Replaces the evalkernel double loop of constructkernelmatrix! (src/RKHS/RKHS.jl:21-31) and the
+// diagonal "+= sigma2" of fitmixtureGP! (src/RKHS/mixtureGP.jl:102-104).  HBM-write bound:
+// 8 * ld^2 / 2 bytes per patch (lower triangle; diagonal 64x64 tiles are written whole and exactly
+// symmetric).  One workgroup = one 64 x 64 tile, one thread = 4 contiguous rows x 4 columns, so a
+// 16-thread row group stores 512 contiguous bytes per column.  Padding rows/columns (index >= n) are
+// written as identity so the padded factorisation stays positive definite.
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void kmat_slab_kernel(const PatchDesc *__restrict__ descs, const double *__restrict__ x,
+                                                        double *__restrict__ A, pmk_kernel_desc th, double sigma2)
+{
+    const PatchDesc pd = descs[blockIdx.y];
+    const int nt64 = pd.ld / 64;
+    const int ntiles = nt64 * (nt64 + 1) / 2;
+    const int t = blockIdx.x;
+    if (t >= ntiles) return;
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = ti * 64 + 4 * tx, j0 = tj * 64 + 4 * ty;
+    const double *xs = x + pd.xoff;
+    double xi[4][D], xj[4][D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const double4_t vi = *reinterpret_cast<const double4_t *>(xs + (int64_t)d * pd.ld + i0);
+        const double4_t vj = *reinterpret_cast<const double4_t *>(xs + (int64_t)d * pd.ld + j0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { xi[a][d] = vi[a]; xj[a][d] = vj[a]; }
+    }
+    double *S = A + pd.aoff;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int j = j0 + b;
+        double4_t o;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int i = i0 + a;
+            double v;
+            if (i < pd.n && j < pd.n) {
+                v = (i >= j) ? kern_eval<D>(th, xi[a], xj[b]) : kern_eval<D>(th, xj[b], xi[a]);
+                if (i == j) v = v + sigma2;
+            } else {
+                v = (i == j) ? 1.0 : 0.0;
+            }
+            o[a] = v;
+        }
+        *reinterpret_cast<double4_t *>(S + i0 + (int64_t)j * pd.ld) = o;
+    }
+}
+
+template <int D>
+static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s)
+{
+    const int nt64 = m->max_nt * (TILE / 64);
+    dim3 grid((unsigned)(nt64 * (nt64 + 1) / 2), (unsigned)m->P);
+    hipLaunchKernelGGL(kmat_slab_kernel<D>, grid, dim3(256), 0, s, m->d_desc, m->d_x, m->d_a, th, sigma2);
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
+#define PMK_DISPATCH_D(D, CALL)                                    \
+    switch (D) {                                                   \
+    case 1: { constexpr int DD = 1; CALL; } break;                 \
+    case 2: { constexpr int DD = 2; CALL; } break;                 \
+    case 3: { constexpr int DD = 3; CALL; } break;                 \
+    case 4: { constexpr int DD = 4; CALL; } break;                 \
+    default: set_error("unsupported input dimension %d (1..%d)", (int)(D), MAX_D); return -2; \
+    }
+
+int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s)
+{
+    int rc = 0;
+    PMK_DISPATCH_D(m->D, rc = launch_slab_D<DD>(m, th, sigma2, s));
+    return rc;
+}
+
+// Dense n x m kernel matrix for the host API (constructkernelmatrix, RKHS.jl:4-34 and :95-110).
+// symmetric: entry (i,j) is evaluated as k(x_max, x_min) -- the lower-triangle value of the
+// reference, mirrored -- so the result is exactly symmetric.
+template <int D>
+__global__ __launch_bounds__(256) void kmat_dense_kernel(pmk_kernel_desc th, int64_t n, const double *__restrict__ xs,
+                                                         int64_t ldx, int64_t mcols, const double *__restrict__ zs,
+                                                         int64_t ldz, double *__restrict__ K, int64_t ldk, int symmetric)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int64_t jb = (int64_t)blockIdx.y * 64 + (threadIdx.x >> 6) * 16;
+    if (i >= n) return;
+    double xi[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xi[d] = xs[d * ldx + i];
+    for (int64_t j = jb; j < jb + 16 && j < mcols; ++j) {
+        double zj[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) zj[d] = zs[d * ldz + j];
+        double v;
+        if (symmetric && i < j) v = kern_eval<D>(th, zj, xi);
+        else v = kern_eval<D>(th, xi, zj);
+        K[i + j * ldk] = v;
+    }
+}
+
+int launch_kernel_matrix_dense(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
+                               int64_t mcols, const double *d_zs, int64_t ldz, double *d_K, int64_t ldk,
+                               bool symmetric, hipStream_t s)
+{
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)((mcols + 63) / 64));
+    PMK_DISPATCH_D(D, hipLaunchKernelGGL(kmat_dense_kernel<DD>, grid, dim3(256), 0, s, th, n, d_xs, ldx, mcols, d_zs,
+                                         ldz, d_K, ldk, symmetric ? 1 : 0));
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// query! of the single-problem path (src/RKHS/RKHS.jl:220-247): Yq[j] = sum_i k(xq_j, x_i) c_i
+template <int D>
+__global__ __launch_bounds__(64) void query_mean_kernel(pmk_kernel_desc th, int64_t n, const double *__restrict__ xs,
+                                                        int64_t ldx, const double *__restrict__ c, int64_t nq,
+                                                        const double *__restrict__ xq, double *__restrict__ yq)
+{
+    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (j >= nq) return;
+    double q[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) q[d] = xq[j * D + d];
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        double xi[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xi[d] = xs[d * ldx + i];
+        s += kern_eval<D>(th, q, xi) * c[i];
+    }
+    yq[j] = s;
+}
+
+int launch_query_mean(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx, const double *d_c,
+                      int64_t nq, const double *d_xq, double *d_yq, hipStream_t s)
+{
+    dim3 grid((unsigned)((nq + 63) / 64));
+    PMK_DISPATCH_D(D, hipLaunchKernelGGL(query_mean_kernel<DD>, grid, dim3(64), 0, s, th, n, d_xs, ldx, d_c, nq, d_xq,
+                                         d_yq));
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// =============================================================================================
+// K5: home leaf + neighbour items per query.  Bit-exact restatement of findpartition
+// (src/patchwork/partition.jl:248-262) and findneighbourpartitions (src/RKHS/mixtureGP.jl:339-405):
+// no FMA contraction, the reference's operation order.  One thread per query; every hyperplane of
+// the tree is visited in pre-order (the reference does not prune either).
+// =============================================================================================
+#pragma clang fp contract(off)
+template <int D>
+__device__ __forceinline__ int find_leaf(const double *__restrict__ hv, const double *__restrict__ hc, int levels,
+                                         int64_t P, const double *x)
+{
+    int node = 0;
+    for (int l = 1; l < levels; ++l) {
+        double u[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) u[d] = hv[(int64_t)node * D + d];
+        node = (dot_seq<D>(u, x) < hc[node]) ? 2 * node + 1 : 2 * node + 2;
+    }
+    return node - (int)(P - 1);
+}
+
+template <int D, bool FILL>
+__global__ __launch_bounds__(256) void plan_kernel(int64_t Nq, const double *__restrict__ xq,
+                                                   const double *__restrict__ hv, const double *__restrict__ hc,
+                                                   const int32_t *__restrict__ pre, int levels, int64_t P, double radius,
+                                                   double delta, int32_t *__restrict__ home_out,
+                                                   int32_t *__restrict__ cnt_out, const int64_t *__restrict__ qoff,
+                                                   int32_t *__restrict__ item_region, double *__restrict__ item_t,
+                                                   int32_t *__restrict__ item_query)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= Nq) return;
+    double p[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) p[d] = xq[j * D + d];
+    const int home = find_leaf<D>(hv, hc, levels, P, p);
+    int count = 0;
+    int64_t base = 0;
+    if (FILL) base = qoff[j];
+    for (int64_t i = 0; i < P - 1; ++i) {
+        const int h = pre[i];
+        double u[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) u[d] = hv[(int64_t)h * D + d];
+        const double c = hc[h];
+        const double tt = -dot_seq<D>(u, p) + c;                 // mixtureGP.jl:361
+        double r0 = (p[0] + tt * u[0]) - p[0];                   // z = p + t.*u ; norm(z - p)   :362,:367
+        double s = r0 * r0;
+#pragma unroll
+        for (int d = 1; d < D; ++d) {
+            double r = (p[d] + tt * u[d]) - p[d];
+            s = s + r * r;
+        }
+        if (sqrt(s) < radius) {
+            const double tp = tt + delta, tm = tt - delta;
+            double z1[D], z2[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { z1[d] = p[d] + tp * u[d]; z2[d] = p[d] + tm * u[d]; }
+            const int r1 = find_leaf<D>(hv, hc, levels, P, z1);   // :374-375
+            const int r2 = find_leaf<D>(hv, hc, levels, P, z2);
+            if ((r2 == home) != (r1 == home)) {                   // xor :388
+                if (FILL) {
+                    item_region[base + count] = (r1 == home) ? r2 : r1;
+                    item_t[base + count] = tt;
+                    item_query[base + count] = (int32_t)j;
+                }
+                ++count;
+            }
+        }
+    }
+    if (FILL) {
+        item_region[base + count] = home;     // home region last (mixtureGP.jl:237-239)
+        item_t[base + count] = 0.0;
+        item_query[base + count] = (int32_t)j;
+    } else {
+        home_out[j] = home;
+        cnt_out[j] = count + 1;
+    }
+}
+#pragma clang fp contract(fast)
+
+static int launch_plan(pmk_query *q, double radius, double delta, bool fill, hipStream_t s)
+{
+    const pmk_model *m = q->m;
+    dim3 grid((unsigned)((q->Nq + 255) / 256));
+    if (fill) {
+        PMK_DISPATCH_D(m->D, hipLaunchKernelGGL((plan_kernel<DD, true>), grid, dim3(256), 0, s, q->Nq, q->d_xq, m->d_hv,
+                                                m->d_hc, m->d_pre, m->levels, m->P_global, radius, delta, q->d_home,
+                                                q->d_cnt, q->d_qoff, q->d_item_region, q->d_item_t, q->d_item_query));
+    } else {
+        PMK_DISPATCH_D(m->D, hipLaunchKernelGGL((plan_kernel<DD, false>), grid, dim3(256), 0, s, q->Nq, q->d_xq, m->d_hv,
+                                                m->d_hc, m->d_pre, m->levels, m->P_global, radius, delta, q->d_home,
+                                                q->d_cnt, q->d_qoff, q->d_item_region, q->d_item_t, q->d_item_query));
+    }
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s) { return launch_plan(q, radius, delta, false, s); }
+int launch_plan_fill(pmk_query *q, double radius, double delta, hipStream_t s) { return launch_plan(q, radius, delta, true, s); }
+
+struct CastI64 {
+    __host__ __device__ int64_t operator()(int32_t v) const { return (int64_t)v; }
+};
+
+// d_out[0..n] = exclusive prefix sums of d_in[0..n) (d_out has n+1 entries); d_in needs n+1 readable
+// entries, the last one is ignored.
+int64_t exclusive_scan_i32_to_i64(const int32_t *d_in, int64_t *d_out, int64_t n, void **tmp, size_t *tmp_bytes,
+                                  hipStream_t s)
+{
+    hipcub::TransformInputIterator<int64_t, CastI64, const int32_t *> it(d_in, CastI64());
+    size_t need = 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, need, it, d_out, (int)(n + 1), s) != hipSuccess) return -1;
+    if (need > *tmp_bytes) {
+        if (*tmp) (void)hipFree(*tmp);
+        if (hipMalloc(tmp, need) != hipSuccess) return -1;
+        *tmp_bytes = need;
+    }
+    if (hipcub::DeviceScan::ExclusiveSum(*tmp, need, it, d_out, (int)(n + 1), s) != hipSuccess) return -1;
+    return 0;
+}
+
+__global__ void iota_kernel(int32_t *v, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
+// region_offsets from the sorted keys + the inverse permutation
+__global__ void region_offsets_kernel(const int32_t *__restrict__ keys, const int32_t *__restrict__ sorted_item,
+                                      int64_t n, int64_t P, int64_t *__restrict__ roff, int32_t *__restrict__ item_pos)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    item_pos[sorted_item[k]] = (int32_t)k;
+    const int cur = keys[k];
+    const int prev = (k == 0) ? -1 : keys[k - 1];
+    for (int r = prev + 1; r <= cur; ++r) roff[r] = k;
+    if (k == n - 1)
+        for (int64_t r = cur + 1; r <= P; ++r) roff[r] = n;
+}
+
+// stable sort of the items by region: deterministic, so every rank of a multi-GPU job derives the
+// same sorted order from the replicated plan
+int launch_sort_items(pmk_query *q, hipStream_t s)
+{
+    const int64_t n = q->total;
+    const pmk_model *m = q->m;
+    if (n == 0) return 0;
+    int32_t *keys_out = nullptr, *iota = nullptr;
+    PMK_HIP(hipMalloc((void **)&keys_out, sizeof(int32_t) * n));
+    PMK_HIP(hipMalloc((void **)&iota, sizeof(int32_t) * n));
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, iota, n);
+    int bits = 1;
+    while (((int64_t)1 << bits) < m->P_global) ++bits;
+    size_t need = 0;
+    PMK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, q->d_item_region, keys_out, iota, q->d_sorted_item, (int)n,
+                                               0, bits, s));
+    if (need > q->tmp_bytes) {
+        if (q->d_tmp) PMK_HIP(hipFree(q->d_tmp));
+        PMK_HIP(hipMalloc(&q->d_tmp, need));
+        q->tmp_bytes = need;
+    }
+    PMK_HIP(hipcub::DeviceRadixSort::SortPairs(q->d_tmp, need, q->d_item_region, keys_out, iota, q->d_sorted_item, (int)n,
+                                               0, bits, s));
+    hipLaunchKernelGGL(region_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys_out,
+                       q->d_sorted_item, n, m->P_global, q->d_roff, q->d_item_pos);
+    PMK_HIP(hipGetLastError());
+    PMK_HIP(hipStreamSynchronize(s));
+    PMK_HIP(hipFree(keys_out));
+    PMK_HIP(hipFree(iota));
+    return 0;
+}
+
+// =============================================================================================
+// K6: mixture weights and blend, src/RKHS/mixtureGP.jl:224-272.  Neighbour weights phi_w(|t|) in
+// hyperplane order, home weight 1 last, normalise, Yq = sum w u, Vq = sum w (v w).
+// =============================================================================================
+__global__ __launch_bounds__(256) void mix_kernel(int64_t q0, int64_t q1, const int64_t *__restrict__ qoff,
+                                                  const double *__restrict__ item_t, const int32_t *__restrict__ item_pos,
+                                                  const double *__restrict__ u, const double *__restrict__ v,
+                                                  pmk_kernel_desc wth, double *__restrict__ w_out,
+                                                  double *__restrict__ yq, double *__restrict__ vq)
+{
+    const int64_t j = q0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= q1) return;
+    const int64_t b = qoff[j], e = qoff[j + 1];
+    double sw = 0.0;
+    for (int64_t it = b; it < e; ++it) {
+        const double w = (it == e - 1) ? 1.0 : profile(wth, fabs(item_t[it]));
+        w_out[it] = w;
+        sw = (it == b) ? w : sw + w;
+    }
+    double y = 0.0, vv = 0.0;
+    for (int64_t it = b; it < e; ++it) {
+        const double w = w_out[it] / sw;
+        const int32_t pos = item_pos[it];
+        const double ui = u[pos], vi = v[pos];
+        y = (it == b) ? w * ui : y + w * ui;
+        vv = (it == b) ? w * (vi * w) : vv + w * (vi * w);
+    }
+    yq[j] = y;
+    vq[j] = vv;
+}
+
+int launch_mix(pmk_query *q, const pmk_kernel_desc &wth, int64_t q0, int64_t q1, hipStream_t s)
+{
+    if (q1 <= q0) return 0;
+    hipLaunchKernelGGL(mix_kernel, dim3((unsigned)((q1 - q0 + 255) / 256)), dim3(256), 0, s, q0, q1, q->d_qoff,
+                       q->d_item_t, q->d_item_pos, q->d_u, q->d_v, wth, q->d_w, q->d_yq, q->d_vq);
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pmk

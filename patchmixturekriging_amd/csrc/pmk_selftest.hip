@@ -1,0 +1,140 @@
+// Self-test kernels (include/pmk_test.h): fragment-layout checks of the fp64 MFMA tile routines and
+// an fp64 MFMA issue-rate microbenchmark (the fp64 matrix peak is not in the local hardware guide;
+// the roofline in bench.py is priced against the datasheet value and this measurement is reported
+// beside it).
+#include "../../include/pmk_test.h"
+#include "pmk_mfma.h"
+
+namespace pmk {
+
+__global__ __launch_bounds__(64) void selftest_gemm_kernel(int K, const double *MI, const double *MJ, double *C)
+{
+    const int lane = threadIdx.x;
+    WaveTile<4, 1> t;
+    t.zero();
+    gemm_nt<4, 1, 4>(t, MI, 128, MJ, 32, K, lane);
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj) {
+                const int I = 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * q) + (fi & 1);
+                const int J = 32 * (fj >> 1) + 2 * (lane & 15) + (fj & 1);
+                C[J + 32 * I] = t.f[fi][fj][q];
+            }
+}
+
+__global__ __launch_bounds__(64) void selftest_trisolve_kernel(const double *Linv, const double *Tin, double *Tout)
+{
+    const int lane = threadIdx.x;
+    WaveTile<4, 1> t;
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj) {
+                const int I = 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * q) + (fi & 1);
+                const int J = 32 * (fj >> 1) + 2 * (lane & 15) + (fj & 1);
+                t.f[fi][fj][q] = Tin[J + 32 * I];
+            }
+    tri_solve_inplace<1>(t, Linv, lane);
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj) {
+                const int I = 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * q) + (fi & 1);
+                const int J = 32 * (fj >> 1) + 2 * (lane & 15) + (fj & 1);
+                Tout[J + 32 * I] = t.f[fi][fj][q];
+            }
+}
+
+// 16 independent accumulators per wave, operands in registers, no memory traffic in the loop
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double *sink)
+{
+    double4_t acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = mfma64(a, b, acc[i]);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456) sink[0] = s;   // keep the loop alive
+}
+
+}  // namespace pmk
+
+using namespace pmk;
+
+extern "C" {
+
+int pmk_selftest_gemm(pmk_ctx *ctx, int K, const double *MI, const double *MJ, double *C)
+{
+    if (!ctx || !MI || !MJ || !C || K < 16 || K % 16) { set_error("pmk_selftest_gemm: bad argument"); return -1; }
+    PMK_HIP(hipSetDevice(ctx->device));
+    double *dI, *dJ, *dC;
+    PMK_HIP(hipMalloc((void **)&dI, sizeof(double) * 128 * K));
+    PMK_HIP(hipMalloc((void **)&dJ, sizeof(double) * 32 * K));
+    PMK_HIP(hipMalloc((void **)&dC, sizeof(double) * 128 * 32));
+    PMK_HIP(hipMemcpy(dI, MI, sizeof(double) * 128 * K, hipMemcpyHostToDevice));
+    PMK_HIP(hipMemcpy(dJ, MJ, sizeof(double) * 32 * K, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(selftest_gemm_kernel, dim3(1), dim3(64), 0, ctx->stream, K, dI, dJ, dC);
+    PMK_HIP(hipGetLastError());
+    PMK_HIP(hipStreamSynchronize(ctx->stream));
+    PMK_HIP(hipMemcpy(C, dC, sizeof(double) * 128 * 32, hipMemcpyDeviceToHost));
+    (void)hipFree(dI); (void)hipFree(dJ); (void)hipFree(dC);
+    return 0;
+}
+
+int pmk_selftest_trisolve(pmk_ctx *ctx, const double *Linv, const double *T_in, double *T_out)
+{
+    if (!ctx || !Linv || !T_in || !T_out) { set_error("pmk_selftest_trisolve: bad argument"); return -1; }
+    PMK_HIP(hipSetDevice(ctx->device));
+    double *dL, *dI, *dO;
+    PMK_HIP(hipMalloc((void **)&dL, sizeof(double) * 128 * 128));
+    PMK_HIP(hipMalloc((void **)&dI, sizeof(double) * 128 * 32));
+    PMK_HIP(hipMalloc((void **)&dO, sizeof(double) * 128 * 32));
+    PMK_HIP(hipMemcpy(dL, Linv, sizeof(double) * 128 * 128, hipMemcpyHostToDevice));
+    PMK_HIP(hipMemcpy(dI, T_in, sizeof(double) * 128 * 32, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(selftest_trisolve_kernel, dim3(1), dim3(64), 0, ctx->stream, dL, dI, dO);
+    PMK_HIP(hipGetLastError());
+    PMK_HIP(hipStreamSynchronize(ctx->stream));
+    PMK_HIP(hipMemcpy(T_out, dO, sizeof(double) * 128 * 32, hipMemcpyDeviceToHost));
+    (void)hipFree(dL); (void)hipFree(dI); (void)hipFree(dO);
+    return 0;
+}
+
+int pmk_selftest_mfma_peak(pmk_ctx *ctx, double *tflops)
+{
+    if (!ctx || !tflops) { set_error("pmk_selftest_mfma_peak: bad argument"); return -1; }
+    PMK_HIP(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    PMK_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    double *sink;
+    PMK_HIP(hipMalloc((void **)&sink, sizeof(double)));
+    const int iters = 4000;
+    const int blocks = prop.multiProcessorCount * 2;
+    hipEvent_t a, b;
+    PMK_HIP(hipEventCreate(&a));
+    PMK_HIP(hipEventCreate(&b));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, 100, sink);   // warm-up
+    PMK_HIP(hipEventRecord(a, ctx->stream));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink);
+    PMK_HIP(hipEventRecord(b, ctx->stream));
+    PMK_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    PMK_HIP(hipEventElapsedTime(&ms, a, b));
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 16.0 * (2.0 * 16 * 16 * 4);
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(sink);
+    return 0;
+}
+
+}  // extern "C"

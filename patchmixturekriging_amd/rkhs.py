@@ -1,0 +1,96 @@
+"""Single-problem RKHS / GP regression: Python mirror of src/RKHS/RKHS.jl:4-34,95-110,182-305 and
+src/RKHS/querying.jl:2-5 over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .context import default_context
+from .kernels import as_points
+
+_dp = C.POINTER(C.c_double)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def constructkernelmatrix(X, theta_or_Z, theta=None):
+    """constructkernelmatrix(X, θ) -> n x n (RKHS.jl:4-34, exactly symmetric);
+    constructkernelmatrix(X, Z, θ) -> n x m (RKHS.jl:95-110).  Returns a HOST matrix
+    (callers apply rank / isposdef to it, examples/IBB1D.jl:39-41)."""
+    if theta is None:
+        theta, Z = theta_or_Z, None
+    else:
+        Z = as_points(theta_or_Z)
+    X = as_points(X)
+    n, D = X.shape
+    m = n if Z is None else Z.shape[0]
+    if Z is not None and Z.shape[1] != D:
+        raise ValueError("X and Z have different dimensions")
+    K = np.empty((n, m), dtype=np.float64, order="F")
+    d = theta.desc()
+    ctx = default_context()
+    _lib.check(ctx.L.pmk_kernel_matrix(ctx.h, C.byref(d), D, n, _d(X), m, _d(Z) if Z is not None else None,
+                                       _d(K), n), "constructkernelmatrix")
+    return K
+
+
+def evalkernel(p, q, theta):
+    """evalkernel(p, q, θ) for points, evalkernel(τ, θ) for a stationary profile (kernel.jl:277-381)"""
+    if theta is None:
+        raise TypeError("evalkernel(p, q, theta) or evalkernel(tau, theta)")
+    p = np.atleast_1d(np.asarray(p, dtype=np.float64))
+    q = np.atleast_1d(np.asarray(q, dtype=np.float64))
+    return float(constructkernelmatrix(p[None, :], q[None, :], theta)[0, 0])
+
+
+def evalprofile(tau, theta):
+    """evalkernel(τ::Real, θ::StationaryKernelType)"""
+    if not getattr(theta, "stationary", False):
+        raise TypeError("the scalar form is defined for stationary kernels")
+    return evalkernel([float(tau)], [0.0], theta)
+
+
+class RKHSProblemType:                      # src/misc/declarations.jl:226-231
+    def __init__(self, c, X, theta, sigma2):
+        self.c = np.asarray(c, dtype=np.float64)
+        self.X = as_points(X)
+        self.theta = theta
+        self.sigma2 = float(sigma2)
+
+
+def fitRKHS_(eta, y):
+    """fitRKHS!(η, y): η.c[:] = (K + σ²I) \\ y   (RKHS.jl:182-217).  One patch through the batched fit."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    assert eta.X.shape[0] > 0 and len(y) > 0           # RKHS.jl:199-200
+    assert eta.X.shape[0] == len(y)                    # RKHS.jl:203
+    from .mixture import fit_patches
+    model, cs, info = fit_patches([eta.X], [y], eta.theta, eta.sigma2)
+    if info[0] != 0:
+        raise np.linalg.LinAlgError("matrix is not positive definite; leading minor %d" % info[0])
+    eta.c[:] = cs[0]
+    return None
+
+
+def query_(Yq, Xq, eta):
+    """query!(Yq, Xq, η): Yq[iq] = dot(k(Xq[iq], X), c)   (RKHS.jl:220-247)"""
+    Xq = as_points(Xq)
+    assert Xq.shape[0] > 0                              # RKHS.jl:225
+    assert np.shape(Yq)[0] == Xq.shape[0]               # RKHS.jl:227
+    n, D = eta.X.shape
+    out = np.empty(Xq.shape[0])
+    d = eta.theta.desc()
+    ctx = default_context()
+    c = np.ascontiguousarray(eta.c, dtype=np.float64)
+    _lib.check(ctx.L.pmk_query_mean(ctx.h, C.byref(d), D, n, _d(eta.X), _d(c), Xq.shape[0], _d(Xq), _d(out)), "query!")
+    Yq[:] = out
+    return None
+
+
+def evalquery(x, c, X, theta):
+    """evalquery(x, c, X, θ): mean at a single point (querying.jl:2-5)"""
+    eta = RKHSProblemType(c, X, theta, 0.0)
+    y = np.empty(1)
+    query_(y, np.atleast_1d(np.asarray(x, dtype=np.float64))[None, :], eta)
+    return float(y[0])

@@ -1,0 +1,122 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/*.h declares,
+validates arguments, and its host BSP (exact integer outputs) agrees bit for bit with the oracle
+and with the golden fixtures.  No device compute is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import patchmixturekriging_amd as pmk
+from patchmixturekriging_amd import _lib
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in ("pmk.h", "pmk_test.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(pmk_[a-z0-9_]+)\s*\(", txt))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    L = pmk.lib()
+    decl = declared_symbols()
+    assert len(decl) >= 40
+    for name in sorted(decl):
+        assert hasattr(L, name), name
+    assert decl == set(_lib.SIGNATURES), decl ^ set(_lib.SIGNATURES)
+    assert L.pmk_version() == 100
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "patchmixturekriging_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("CPU oracle", ""), os.path.join(dirpath, f)
+
+
+def test_argument_errors_are_reported():
+    L = pmk.lib()
+    h = C.c_void_p()
+    X = np.zeros((4, 2))
+    assert L.pmk_bsp_build(2, 4, X.ctypes.data_as(C.POINTER(C.c_double)), 1, 1, C.byref(h)) < 0   # levels >= 2
+    assert b"levels" in L.pmk_last_error()
+    assert L.pmk_bsp_build(2, 1, X.ctypes.data_as(C.POINTER(C.c_double)), 3, 1, C.byref(h)) < 0   # N < 2^(levels-1)
+    assert L.pmk_bsp_build(9, 4, X.ctypes.data_as(C.POINTER(C.c_double)), 2, 1, C.byref(h)) < 0   # D too large
+    with pytest.raises(pmk.PmkError):
+        pmk.setuppartition(np.zeros((4, 2)), 1)
+    # identical points: a child node ends up empty -> reported, not crashed
+    with pytest.raises(pmk.PmkError):
+        pmk.setuppartition(np.zeros((64, 2)), 4)
+
+
+@pytest.mark.parametrize("name", ["bsp_2d.npz", "bsp_3d.npz"])
+def test_host_bsp_matches_golden_and_oracle(golden, name):
+    g = golden(name)
+    X, levels = g["X"], int(g["levels"])
+    root, X_parts, X_parts_inds = pmk.setuppartition(X, levels)
+    hv, hc = pmk.partition.hyperplane_arrays(root)
+    assert np.array_equal(hv, g["hp_v"]) and np.array_equal(hc, g["hp_c"])
+    assert np.array_equal(np.concatenate(X_parts_inds), g["leaf_inds"])
+    assert np.array_equal(np.cumsum([0] + [len(i) for i in X_parts_inds]), g["leaf_off"])
+    for l, (xp, ip) in enumerate(zip(X_parts, X_parts_inds)):
+        assert np.array_equal(xp, X[ip])                       # partition.jl:151-153
+    X_set, X_set_inds, lists, problematic = pmk.organizetrainingsets(root, levels, X, float(g["eps"]))
+    assert np.array_equal(np.concatenate(X_set_inds), g["set_inds"])
+    assert np.array_equal(np.concatenate(lists), g["lists"])
+    assert problematic == []
+    home = np.array([pmk.findpartition(x, root, levels) for x in g["Xq"]])
+    assert np.array_equal(home, g["home"])
+    hps = pmk.fetchhyperplanes(root)
+    assert len(hps) == len(X_parts) - 1                        # patchGP_partitioning.jl:198
+    nb_reg, nb_t = [], []
+    for x, h in zip(g["Xq"], home):
+        reg, ts, zs, keep = pmk.findneighbourpartitions(x, float(g["radius"]), root, levels, hps, h, delta=float(g["delta"]))
+        nb_reg += list(reg); nb_t += list(ts[keep])
+        d = np.linalg.norm(zs[keep] - x, axis=1)
+        assert np.all(np.abs(d - np.abs(ts[keep])) < 1e-10)    # patchGP_partitioning.jl:214-215
+    assert np.array_equal(nb_reg, g["nb_reg"]) and np.array_equal(nb_t, g["nb_t"])
+    # the oracle agrees too (two independent implementations of the same arithmetic)
+    ob = O.BSP(X, levels)
+    ov, oc = ob.hyperplanes()
+    assert np.array_equal(ov, hv) and np.array_equal(oc, hc)
+
+
+def test_host_bsp_random_vs_oracle_large():
+    rng = np.random.Generator(np.random.PCG64(25))
+    N, levels = 40000, 8
+    X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+    root, parts, inds = pmk.setuppartition(X, levels)
+    ob = O.BSP(X, levels)
+    off, oinds = ob.leaves()
+    assert np.array_equal(np.concatenate(inds), oinds)
+    ov, oc = ob.hyperplanes()
+    hv, hc = pmk.partition.hyperplane_arrays(root)
+    assert np.array_equal(ov, hv) and np.array_equal(oc, hc)
+    _, sinds, lists, _ = pmk.organizetrainingsets(root, levels, X, 0.11)
+    ooff, osinds, oloff, olists = ob.assign(X, 0.11)
+    assert np.array_equal(np.concatenate(sinds), osinds) and np.array_equal(np.concatenate(lists), olists)
+    # shipping the tree through its hyperplanes reproduces the searches
+    r2 = pmk.tree_from_hyperplanes(2, levels, hv, hc)
+    q = rng.uniform(-5, 5, (200, 2))
+    assert [pmk.findpartition(x, r2) for x in q] == [pmk.findpartition(x, root) for x in q]
+
+
+def test_tree_view_fields():
+    # fields read by the reference's plotting helpers (visualize_2D.jl:23,46-47,60-78)
+    X = np.random.default_rng(1).uniform(0, 1, (64, 2))
+    root, parts, inds = pmk.setuppartition(X, 3)
+    assert root.parent is None and root.left.parent is root and root.right.parent is root
+    assert root.data.hp.v.shape == (2,) and isinstance(root.data.hp.c, float)
+    leaves = [root.left.left, root.left.right, root.right.left, root.right.right]
+    assert [l.data.index for l in leaves] == [0, 1, 2, 3]      # dev/btree_easy.jl:56-68 left before right
+    assert all(not l.data.hp.isdefined() and l.children() == () for l in leaves)
+    assert np.array_equal(leaves[2].data.global_X_indices, inds[2])

@@ -1,0 +1,415 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the CPU oracle on the same seeded inputs and against the committed golden fixtures.
+
+Tolerances (fp64): integer outputs exact; K entries <= 4 ulp;
+c by residual |Uc - y| / (|U||c| + |y|) <= 1e-13; Yq within 1e-7 max(1,|Yq|);
+Vq within 1e-9 + 1e-5 Vq.
+"""
+import numpy as np
+import pytest
+
+import patchmixturekriging_amd as pmk
+from patchmixturekriging_amd import mixture as M
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = [  # (product kernel, oracle kernel)
+    (pmk.Spline34KernelType(1 / 4.0), O.kernel(O.SPLINE34, 1 / 4.0)),
+    (pmk.Spline12KernelType(0.3), O.kernel(O.SPLINE12, 0.3)),
+    (pmk.Spline32KernelType(0.3), O.kernel(O.SPLINE32, 0.3)),
+    (pmk.GaussianKernel1DType(0.7), O.kernel(O.GAUSSIAN, 0.7)),
+    (pmk.RationalQuadraticKernelType(1.3), O.kernel(O.RQ, 1.3)),
+    (pmk.TunableRationalQuadraticKernelType(1.3, 0.4), O.kernel(O.TRQ, 1.3, 0.4)),
+]
+BB_PAIRS = [
+    (pmk.BrownianBridge10(1.0), O.kernel(O.BB10, 1.0)),
+    (pmk.BrownianBridge20(1.0), O.kernel(O.BB20, 1.0)),
+    (pmk.BrownianBridge1eps(4.5), O.kernel(O.BB1EPS, 4.5)),
+    (pmk.BrownianBridge2eps(2.5), O.kernel(O.BB2EPS, 2.5)),
+    (pmk.BrownianBridgeSemiInfDomain(pmk.BrownianBridge10(1.0)), O.kernel(O.BB10, 1.0, flags=O.FLAG_SEMIINF)),
+]
+
+
+def ulps(a, b):
+    return np.abs(a - b) / np.spacing(np.maximum(np.abs(a), np.abs(b)))
+
+
+def oracle_f(X):
+    A = np.array([[1.0, 0.4], [0.4, 1.0]]) * 0.1              # examples/mixGP.jl:44-48
+    q = np.einsum("ni,ij,nj->n", X, A, X)
+    return np.sinc((q / 3.2) ** 2) * (np.linalg.norm(X, axis=1) / 4) ** 3
+
+
+# ------------------------------------------------------------------------------------ MFMA tile algebra
+def test_mfma_fragment_layout_gemm():
+    ctx = pmk.default_context()
+    rng = np.random.default_rng(0)
+    for K in (16, 128, 272):
+        MI = rng.integers(-8, 9, (K, 128)).astype(np.float64)      # asymmetric integer data: exact
+        MJ = rng.integers(-8, 9, (K, 32)).astype(np.float64)
+        C_out = np.empty((128, 32))
+        import ctypes as C
+        dp = C.POINTER(C.c_double)
+        rc = ctx.L.pmk_selftest_gemm(ctx.h, K, MI.ctypes.data_as(dp), MJ.ctypes.data_as(dp), C_out.ctypes.data_as(dp))
+        assert rc == 0, ctx.L.pmk_last_error()
+        assert np.array_equal(C_out, MI.T @ MJ)                     # C[I][J] = sum_k MI[k][I] MJ[k][J]
+
+
+def test_mfma_trisolve_in_registers():
+    import ctypes as C
+    ctx = pmk.default_context()
+    rng = np.random.default_rng(1)
+    Linv = np.tril(rng.integers(-4, 5, (128, 128))).astype(np.float64)
+    T = rng.integers(-4, 5, (128, 32)).astype(np.float64)
+    out = np.empty((128, 32))
+    dp = C.POINTER(C.c_double)
+    Lf = np.asfortranarray(Linv)
+    rc = ctx.L.pmk_selftest_trisolve(ctx.h, Lf.ctypes.data_as(dp), T.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    assert rc == 0, ctx.L.pmk_last_error()
+    assert np.array_equal(out, Linv @ T)
+
+
+def test_mfma_peak_is_measured():
+    import ctypes as C
+    ctx = pmk.default_context()
+    tf = C.c_double()
+    assert ctx.L.pmk_selftest_mfma_peak(ctx.h, C.byref(tf)) == 0
+    print("fp64 MFMA sustained: %.1f TFLOP/s" % tf.value)
+    assert 20.0 < tf.value < 200.0
+
+
+# ------------------------------------------------------------------------------------ K1 kernel matrix
+@pytest.mark.parametrize("D", [1, 2, 3])
+def test_kernel_matrix_vs_oracle(D):
+    rng = np.random.default_rng(10 + D)
+    X = rng.uniform(-3, 3, (300, D))
+    Z = rng.uniform(-3, 3, (77, D))
+    for th, oth in PAIRS:
+        K = pmk.constructkernelmatrix(X, th)
+        Ko = O.kernel_matrix(oth, X)
+        assert np.array_equal(K, K.T)                              # RKHS.jl:27-31 mirror
+        nz = Ko != 0
+        assert np.all((K == 0) == (Ko == 0) | (np.abs(K - Ko) < 1e-18))
+        assert ulps(K[nz], Ko[nz]).max() <= 4 or np.abs(K - Ko).max() < 1e-18, (th, ulps(K[nz], Ko[nz]).max())
+        Kc = pmk.constructkernelmatrix(X, Z, th)
+        Kco = O.cross_kernel_matrix(oth, X, Z)
+        nz = Kco != 0
+        assert ulps(Kc[nz], Kco[nz]).max() <= 4
+
+
+def test_kernel_matrix_brownian_bridge():
+    rng = np.random.default_rng(3)
+    for D in (1, 2):
+        X = rng.uniform(0.01, 0.99, (150, D))
+        for th, oth in BB_PAIRS:
+            K = pmk.constructkernelmatrix(X, th)
+            Ko = O.kernel_matrix(oth, X)
+            assert np.array_equal(K, K.T)
+            if oth.family in (O.BB10, O.BB20):
+                assert np.array_equal(K, Ko)                       # only +,-,*,min: bit exact
+            else:
+                assert np.abs(K - Ko).max() <= 1e-12 * np.abs(Ko).max()
+
+
+def test_modulated_sqexp_1d_and_evalkernel():
+    th, oth = pmk.ModulatedSqExpKernelType(0.9, 3.1), O.kernel(O.MODSQEXP, 0.9, 3.1)
+    x = np.linspace(-1, 1, 40)
+    assert np.abs(pmk.constructkernelmatrix(x, th) - O.kernel_matrix(oth, x)).max() < 1e-15
+    s34 = pmk.Spline34KernelType(1.0)
+    assert pmk.evalkernel([0.0, 0.0], [0.0, 0.0], s34) == 1.0      # kernel.jl:297-298
+    assert pmk.evalkernel([0.0], [1.0], s34) == 0.0
+    assert pmk.evalprofile(0.5, s34) == pytest.approx(20.75 * 2.0 ** -6 / 3.0, rel=1e-15)
+    assert pmk.evalkernel([0.25], [0.5], pmk.BrownianBridge10(1.0)) == 0.125
+
+
+# ------------------------------------------------------------------------------------ fit
+def _check_fit(model, r, X, y, th_o, sigma2, L_tol=1e-8):
+    f = O.fit_patch(th_o, X, y, sigma2, want_K=True)
+    assert f["info"] == 0
+    n = len(y)
+    U = f["K"] + sigma2 * np.eye(n)
+    c = model.get(r, M.GET_C)
+    L = model.get(r, M.GET_L)
+    res = np.linalg.norm(U @ c - y) / (np.linalg.norm(U) * np.linalg.norm(c) + np.linalg.norm(y))
+    assert res <= 1e-13, res
+    assert np.all(np.triu(L, 1) == 0)
+    assert np.linalg.norm(L @ L.T - U) / np.linalg.norm(U) <= 1e-14
+    assert np.abs(L - f["L"]).max() <= L_tol
+    assert np.linalg.norm(c - f["c_chol"]) / np.linalg.norm(f["c_chol"]) <= 1e-6
+    K = model.get(r, M.GET_K)                                   # U_set entry, rebuilt on demand
+    assert np.array_equal(K, K.T) and ulps(K[f["K"] != 0], f["K"][f["K"] != 0]).max() <= 4
+    # inverted diagonal blocks really invert the diagonal blocks of L
+    Li = model.get(r, M.GET_LINV_DIAG)
+    for b in range(Li.shape[0]):
+        lo, hi = 128 * b, min(128 * (b + 1), n)
+        blk = L[lo:hi, lo:hi]
+        assert np.abs(Li[b][:hi - lo, :hi - lo] @ blk - np.eye(hi - lo)).max() < 1e-9
+        assert np.all(np.triu(Li[b], 1) == 0)
+    return c, L
+
+
+def test_fit_variable_sizes_vs_oracle():
+    # ragged patch sizes around the tile edge, including n = 1 (edge cases of the padded slabs)
+    rng = np.random.default_rng(21)
+    sizes = [1, 5, 127, 128, 129, 300, 640, 1000]
+    Xs = [rng.uniform(-4, 4, (n, 2)) for n in sizes]
+    ys = [np.sin(x[:, 0]) * np.cos(0.5 * x[:, 1]) for x in Xs]
+    th, oth = pmk.Spline34KernelType(1 / 3.0), O.kernel(O.SPLINE34, 1 / 3.0)
+    model, cs, info = pmk.fit_patches(Xs, ys, th, 1e-5)
+    assert np.all(info == 0)
+    for r in range(len(sizes)):
+        c, _ = _check_fit(model, r, Xs[r], ys[r], oth, 1e-5)
+        assert np.array_equal(c, cs[r])
+
+
+def test_fit_3d_and_other_kernels():
+    rng = np.random.default_rng(22)
+    Xs = [rng.uniform(0, 1, (260, 3)), rng.uniform(0, 1, (131, 3))]
+    ys = [x.sum(1) ** 2 for x in Xs]
+    for th, oth in [(pmk.Spline32KernelType(0.8), O.kernel(O.SPLINE32, 0.8)),
+                    (pmk.GaussianKernel1DType(9.0), O.kernel(O.GAUSSIAN, 9.0))]:
+        model, cs, info = pmk.fit_patches(Xs, ys, th, 1e-4)
+        assert np.all(info == 0)
+        for r in range(2):
+            _check_fit(model, r, Xs[r], ys[r], oth, 1e-4, L_tol=1e-7)
+
+
+def test_not_positive_definite_is_reported():
+    # duplicate points and sigma2 = 0: cholesky(U) of the reference throws PosDefException (mixtureGP.jl:109)
+    X = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 0.0], [0.5, 0.5]])
+    good = np.random.default_rng(0).uniform(-1, 1, (200, 2))
+    th = pmk.Spline34KernelType(0.2)
+    model, cs, info = pmk.fit_patches([good, X], [np.ones(200), np.ones(4)], th, 0.0)
+    f = O.fit_patch(O.kernel(O.SPLINE34, 0.2), X, np.ones(4), 0.0)
+    assert info[0] == 0 and info[1] == 3 and f["info"] in (3, -1)
+    eta = pmk.MixtureGPType([good, X], [])
+    with pytest.raises(pmk.PosDefException):
+        pmk.fitmixtureGP_(eta, [np.ones(200), np.ones(4)], th, 0.0)
+
+
+def test_ibb1d_plumbing(golden):
+    # examples/IBB1D.jl:19-62 with the fixture's N
+    g = golden("ibb1d.npz")
+    th = pmk.BrownianBridge10(1.0)
+    X = g["x"][:, None]
+    K = pmk.constructkernelmatrix(X, th)
+    assert np.abs(K - g["K"]).max() < 1e-16
+    assert np.linalg.matrix_rank(K) == len(X) and np.all(np.linalg.eigvalsh(K) > 0)   # IBB1D.jl:39-41
+    eta = pmk.RKHSProblemType(np.zeros(len(X)), X, th, float(g["sigma2"]))
+    pmk.fitRKHS_(eta, g["y"])
+    U = K + float(g["sigma2"]) * np.eye(len(X))
+    assert np.linalg.norm(U @ eta.c - g["y"]) / (np.linalg.norm(U) * np.linalg.norm(eta.c)) < 1e-13
+    yq = np.empty(len(g["xq"]))
+    pmk.query_(yq, g["xq"][:, None], eta)
+    assert np.abs(yq - g["yq"]).max() < 1e-7
+    oc = O.fit_rkhs(O.kernel(O.BB10, 1.0), X, g["y"], float(g["sigma2"]))
+    assert np.abs(yq - O.query_rkhs(O.kernel(O.BB10, 1.0), X, oc, g["xq"][:, None])).max() < 1e-7
+    with pytest.raises(AssertionError):
+        pmk.query_(np.empty(3), g["xq"][:, None], eta)          # RKHS.jl:227 size(Yq)==size(Xq)
+
+
+# ------------------------------------------------------------------------------------ predict
+def _mixgp_case(N, levels, eps, a, sigma2, radius, delta, nq, seed, lo=(-5, -10), hi=(5, 10)):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = np.stack([rng.uniform(lo[d], hi[d], N) for d in range(len(lo))], 1)
+    y = oracle_f(X) if X.shape[1] == 2 else np.sin(3 * X.sum(1))
+    Xq = np.stack([rng.uniform(lo[d], hi[d], nq) for d in range(len(lo))], 1)
+    return X, y, Xq
+
+
+def _run_both(X, y, Xq, levels, eps, a, sigma2, radius, delta):
+    th, wth = pmk.Spline34KernelType(a), pmk.Spline34KernelType(1 / radius)
+    oth, owth = O.kernel(O.SPLINE34, a), O.kernel(O.SPLINE34, 1 / radius)
+    root, X_parts, _ = pmk.setuppartition(X, levels)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, X, eps)
+    hps = pmk.fetchhyperplanes(root)
+    eta = pmk.MixtureGPType(X_set, hps)
+    pmk.fitmixtureGP_(eta, [y[i] for i in X_set_inds], th, sigma2)
+    Yq, Vq = np.empty(0), np.empty(0)
+    dbg = pmk.MixtureGPDebugType(1.0)
+    pmk.querymixtureGP_(Yq, Vq, Xq, eta, root, levels, radius, delta, th, sigma2, wth, dbg, debug_flag=True)
+    # oracle on the same sets
+    ob = O.BSP(X, levels)
+    fits = [O.fit_patch(oth, xs, y[i], sigma2) for xs, i in zip(X_set, X_set_inds)]
+    oY, oV, ohome, ooff, oreg, ots = O.query_mixture(ob, oth, owth, X_set, [f["c_lu"] for f in fits],
+                                                     [f["L"] for f in fits], Xq, radius, delta, debug=True, nthreads=8)
+    return (Yq, Vq, dbg, eta), (oY, oV, ohome, ooff, oreg, ots, fits)
+
+
+def _compare(gpu, ora):
+    Yq, Vq, dbg, eta = gpu
+    oY, oV, ohome, ooff, oreg, ots, fits = ora
+    # integer outputs bit exact: home leaf, neighbour lists (order = hyperplane order)
+    assert np.array_equal(np.array(dbg.p_region_ind_set), ohome)
+    assert np.array_equal(np.concatenate([r for r in dbg.region_inds_set] + [np.empty(0, np.int64)]), oreg)
+    assert [len(r) for r in dbg.region_inds_set] == list(np.diff(ooff))
+    assert np.all(np.abs(Yq - oY) <= 1e-7 * np.maximum(1, np.abs(oY))), np.abs(Yq - oY).max()
+    assert np.all(np.abs(Vq - oV) <= 1e-9 + 1e-5 * oV), (np.abs(Vq - oV) / oV).max()
+    # debug struct contract (examples/helpers/visualization.jl:163-172): home region last, weight 1
+    for j in range(0, len(Yq), max(1, len(Yq) // 50)):
+        assert len(dbg.u_set[j]) == len(dbg.w_tilde_set[j]) == len(dbg.region_inds_set[j]) + 1
+        assert dbg.w_tilde_set[j][-1] == 1.0
+        w = dbg.w_tilde_set[j] / dbg.w_tilde_set[j].sum()
+        assert abs(w @ dbg.u_set[j] - Yq[j]) <= 1e-12 * max(1, abs(Yq[j]))
+        assert abs(w @ (dbg.v_set[j] * w) - Vq[j]) <= 1e-12 * max(1e-12, Vq[j]) + 1e-18
+
+
+def test_mixture_small_vs_oracle():
+    X, y, Xq = _mixgp_case(1500, 4, 0.6, 1 / 4.0, 1e-5, 0.5, 1e-5, 700, 25)
+    gpu, ora = _run_both(X, y, Xq, 4, 0.6, 1 / 4.0, 1e-5, 0.5, 1e-5)
+    _compare(gpu, ora)
+    assert np.diff(ora[3]).max() >= 2          # some query blends three regions
+
+
+def test_mixture_example_defaults_vs_oracle():
+    # examples/mixGP.jl:32-35,108,135,169,174: N = 850, levels 3, eps 1.5, Spline34(1/15), radius 0.3
+    X, y, Xq = _mixgp_case(850, 3, 1.5, 1 / 15, 1e-5, 0.3, 1e-5, 2000, 25)
+    gpu, ora = _run_both(X, y, Xq, 3, 1.5, 1 / 15, 1e-5, 0.3, 1e-5)
+    _compare(gpu, ora)
+
+
+def test_mixture_golden_fixture(golden):
+    g, m = golden("bsp_2d.npz"), golden("mixgp_2d.npz")
+    X, levels = g["X"], int(g["levels"])
+    th, wth = pmk.Spline34KernelType(float(m["a"])), pmk.Spline34KernelType(1 / float(g["radius"]))
+    root, _, _ = pmk.setuppartition(X, levels)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, X, float(g["eps"]))
+    eta = pmk.MixtureGPType(X_set, pmk.fetchhyperplanes(root))
+    pmk.fitmixtureGP_(eta, [m["y"][i] for i in X_set_inds], th, float(m["sigma2"]))
+    c = np.concatenate(eta.c_set)
+    assert np.linalg.norm(c - m["c"]) / np.linalg.norm(m["c"]) < 1e-6
+    assert np.abs(eta.L_set[0] - m["L0"]).max() < 1e-9
+    Yq, Vq, dbg = pmk.querymixtureGP(g["Xq"], eta, root, levels, float(g["radius"]), float(g["delta"]), th,
+                                     float(m["sigma2"]), wth, debug_flag=True)
+    assert np.array_equal(np.array(dbg.p_region_ind_set), g["home"])
+    assert np.array_equal(np.concatenate(dbg.region_inds_set), g["nb_reg"])
+    assert np.all(np.abs(Yq - m["Yq"]) <= 1e-7 * np.maximum(1, np.abs(m["Yq"])))
+    assert np.all(np.abs(Vq - m["Vq"]) <= 1e-9 + 1e-5 * m["Vq"])
+
+
+def test_mixture_3d_golden_tree(golden):
+    g = golden("bsp_3d.npz")
+    X, levels = g["X"], int(g["levels"])
+    y = np.sin(3 * X.sum(1))
+    th, wth = pmk.Spline34KernelType(1.2), pmk.Spline34KernelType(1 / float(g["radius"]))
+    oth, owth = O.kernel(O.SPLINE34, 1.2), O.kernel(O.SPLINE34, 1 / float(g["radius"]))
+    root, _, _ = pmk.setuppartition(X, levels)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, X, float(g["eps"]))
+    eta = pmk.MixtureGPType(X_set, pmk.fetchhyperplanes(root))
+    pmk.fitmixtureGP_(eta, [y[i] for i in X_set_inds], th, 1e-4)
+    Yq, Vq, dbg = pmk.querymixtureGP(g["Xq"], eta, root, levels, float(g["radius"]), float(g["delta"]), th, 1e-4, wth,
+                                     debug_flag=True)
+    assert np.array_equal(np.array(dbg.p_region_ind_set), g["home"])
+    assert np.array_equal(np.concatenate(dbg.region_inds_set), g["nb_reg"])
+    ob = O.BSP(X, levels)
+    fits = [O.fit_patch(oth, xs, y[i], 1e-4) for xs, i in zip(X_set, X_set_inds)]
+    oY, oV = O.query_mixture(ob, oth, owth, X_set, [f["c_lu"] for f in fits], [f["L"] for f in fits], g["Xq"],
+                             float(g["radius"]), float(g["delta"]), nthreads=8)
+    assert np.all(np.abs(Yq - oY) <= 1e-7 * np.maximum(1, np.abs(oY)))
+    assert np.all(np.abs(Vq - oV) <= 1e-9 + 1e-5 * oV)
+
+
+def test_query_edge_cases():
+    X, y, _ = _mixgp_case(600, 3, 0.4, 1 / 4.0, 1e-5, 0.5, 1e-5, 1, 3)
+    th, wth = pmk.Spline34KernelType(1 / 4.0), pmk.Spline34KernelType(2.0)
+    root, _, _ = pmk.setuppartition(X, 3)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, 3, X, 0.4)
+    eta = pmk.MixtureGPType(X_set, pmk.fetchhyperplanes(root))
+    pmk.fitmixtureGP_(eta, [y[i] for i in X_set_inds], th, 1e-5)
+    # single query vector form (mixtureGP.jl:120-135) and a far-away point: mean 0, variance 1
+    Yq, Vq, _ = pmk.querymixtureGP(np.array([500.0, 500.0]), eta, root, 3, 0.5, 1e-5, th, 1e-5, wth)
+    assert Yq[0] == 0.0 and Vq[0] == 1.0
+    # a training point is interpolated and its variance sits near the noise floor
+    Yq, Vq, _ = pmk.querymixtureGP(X[:257], eta, root, 3, 0.5, 1e-5, th, 1e-5, wth)
+    assert np.abs(Yq - y[:257]).max() < 1e-2 and np.all(Vq >= 1e-12) and np.all(Vq < 1e-3)
+    # caller's buffers are resized (mixtureGP.jl:179-180)
+    Y2, V2 = np.empty(3), np.empty(1)
+    pmk.querymixtureGP_(Y2, V2, X[:257], eta, root, 3, 0.5, 1e-5, th, 1e-5, wth, pmk.MixtureGPDebugType(1.0))
+    assert len(Y2) == len(V2) == 257 and np.array_equal(Y2, Yq)
+
+
+# ------------------------------------------------------------------------------------ full-size properties
+def test_config_B_and_strip_boundaries():
+    # BASELINE config B: 16 BSP patches x 1000 points, fp64 (eps = 0 -> uniform n); enough queries that
+    # regions need several 128-column strips, ragged at the end
+    X, y, Xq = _mixgp_case(16000, 5, 0.0, 1 / 15, 1e-5, 0.3, 1e-5, 6000, 25)
+    gpu, ora = _run_both(X, y, Xq, 5, 0.0, 1 / 15, 1e-5, 0.3, 1e-5)
+    _compare(gpu, ora)
+    eta = gpu[3]
+    assert [len(x) for x in eta.X_parts] == [1000] * 16
+    for r in (0, 7, 15):
+        f = ora[6][r]
+        assert np.abs(eta.L_set[r] - f["L"]).max() < 1e-8
+
+
+@pytest.mark.timeout(900)
+def test_config_C_full_size_properties():
+    """BASELINE config C (headline): 256 patches x 2000 points.  The oracle needs ~10 s per patch at this
+    size, so the full batch is checked through size-independent properties and three patches plus a
+    sample of queries against the oracle."""
+    N, levels = 512000, 9
+    rng = np.random.Generator(np.random.PCG64(25))
+    X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+    y = oracle_f(X)
+    th, wth = pmk.Spline34KernelType(1 / 15), pmk.Spline34KernelType(1 / 0.088)
+    oth = O.kernel(O.SPLINE34, 1 / 15)
+    root, X_parts, X_parts_inds = pmk.setuppartition(X, levels)
+    assert [len(p) for p in X_parts] == [2000] * 256
+    model = pmk.DeviceModel(X_parts, [y[i] for i in X_parts_inds])
+    model.fit(th, 1e-5)
+    assert np.all(model.info() == 0)
+    for r in (0, 101, 255):
+        Xr, yr = X_parts[r], y[X_parts_inds[r]]
+        K = O.kernel_matrix(oth, Xr)
+        U = K + 1e-5 * np.eye(2000)
+        L, c = model.get(r, M.GET_L), model.get(r, M.GET_C)
+        assert np.linalg.norm(L @ L.T - U) / np.linalg.norm(U) <= 1e-14
+        assert np.linalg.norm(U @ c - yr) / (np.linalg.norm(U) * np.linalg.norm(c) + np.linalg.norm(yr)) <= 1e-13
+    # linearity of the fit in y: c(y1 + 2 y2) = c(y1) + 2 c(y2)
+    c1 = [model.get(r, M.GET_C) for r in (3, 200)]
+    y2 = [np.cos(x[:, 0]) for x in X_parts]
+    model.set_targets(y2); model.fit(th, 1e-5)
+    c2 = [model.get(r, M.GET_C) for r in (3, 200)]
+    model.set_targets([a + 2 * b for a, b in zip([y[i] for i in X_parts_inds], y2)]); model.fit(th, 1e-5)
+    c3 = [model.get(r, M.GET_C) for r in (3, 200)]
+    for a, b, c in zip(c1, c2, c3):
+        assert np.linalg.norm(c - (a + 2 * b)) / np.linalg.norm(c) < 1e-6
+    model.set_targets([y[i] for i in X_parts_inds]); model.fit(th, 1e-5)
+    # predict 200k uniform queries; integer outputs against the oracle for all, values for a sample
+    Nq = 200000
+    Xq = np.stack([rng.uniform(-5, 5, Nq), rng.uniform(-10, 10, Nq)], 1)
+    model.set_bsp(root, 0)
+    q = pmk.DeviceQuery(model, Xq)
+    total = q.plan(0.088, 1e-5)
+    q.items(th); q.mix(wth)
+    Yq, Vq = q.fetch()
+    dbg = q.debug()
+    ob = O.BSP(X, levels)
+    sample = rng.choice(Nq, 3000, replace=False)
+    for j in sample[:1000]:
+        h = ob.findpartition(Xq[j])
+        reg, ts, _, keep = ob.neighbours(Xq[j], 0.088, 1e-5, h)
+        s = slice(dbg["item_offsets"][j], dbg["item_offsets"][j + 1])
+        assert dbg["home"][j] == h and np.array_equal(dbg["item_region"][s][:-1], reg)
+        assert np.array_equal(dbg["item_t"][s][:-1], ts[keep])
+    assert 1.2 < total / Nq < 1.8                               # ~1.44 active regions/query
+    assert np.all(np.isfinite(Yq)) and np.all(Vq >= 1e-12) and np.all(Vq <= 1.0 + 1e-9)
+    w = dbg["item_w"]
+    assert np.all((w >= 0) & (w <= 1.0))
+    # values: a handful of queries against oracle queryinner with factors pulled from the device
+    cache = {}
+    worst_y = worst_v = 0.0
+    for j in sample[:40]:
+        s = slice(dbg["item_offsets"][j], dbg["item_offsets"][j + 1])
+        us, vs = [], []
+        for r in dbg["item_region"][s]:
+            if r not in cache:
+                cache[r] = (model.get(int(r), M.GET_C), model.get(int(r), M.GET_L))
+            mu, var = O.queryinner(oth, X_parts[r], cache[r][0], cache[r][1], Xq[j])
+            us.append(mu); vs.append(var)
+        ww = dbg["item_w"][s] / dbg["item_w"][s].sum()
+        yj, vj = ww @ np.array(us), ww @ (np.array(vs) * ww)
+        worst_y = max(worst_y, abs(Yq[j] - yj) / max(1, abs(yj)))
+        worst_v = max(worst_v, abs(Vq[j] - vj) / (1e-9 + 1e-5 * vj))
+    assert worst_y <= 1e-7 and worst_v <= 1.0, (worst_y, worst_v)
