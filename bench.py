@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the per-patch GP hot path on MI355X.
+
+Metric (BASELINE.json): patch-solves/s (+ predict-points/s), 256 patches x 2k points per GPU, fp64,
+2-D Spline34 mixGP (config C).  One "step" = one pass of the hot path over one batch of synthetic
+input that is already resident in HBM:
+    fit step     : kernel-matrix build + Cholesky + weight solves for every patch of this rank
+    predict step : partition search + work-item plan, per-(query, region) prediction, all-gather of
+                   the per-item (u, v) across ranks (RCCL), mixture -- for every query of the job
+`value` = patch-solves/s over all ranks (fit steps timed as the contract says: W warm-up steps, K
+timed steps between barrier + synchronize, max over ranks).  predict-points/s is timed the same way
+in a second loop and reported beside it.  N GPUs: weak scaling -- every rank owns 256 leaves of one
+shared BSP tree (no data-path collective in fit; one all-gather in predict).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nq NQ] [--no-cpu]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix/vector peak (not in the local guide)
+
+
+def oracle_f(X):
+    A = np.array([[1.0, 0.4], [0.4, 1.0]]) * 0.1              # examples/mixGP.jl:44-48
+    q = np.einsum("ni,ij,nj->n", X, A, X)
+    return np.sinc((q / 3.2) ** 2) * (np.linalg.norm(X, axis=1) / 4) ** 3
+
+
+def chol_flops(n):
+    """algorithmic flops of one patch-solve's factor + solves: n^3/3 + 2 n^2"""
+    return n ** 3 / 3.0 + 2.0 * n ** 2
+
+
+def panel_flops(ld, tile=128):
+    """flops executed by chol_panel_kernel over one patch: per step k the rows below the diagonal block
+    get a GEMM of depth 128 k and a triangular 128-wide solve"""
+    nt = ld // tile
+    f = 0.0
+    for k in range(nt - 1):
+        rows = ld - (k + 1) * tile
+        f += 2.0 * rows * tile * (tile * k) + rows * tile * tile
+    return f
+
+
+class DevArray:
+    """a device buffer owned by the library, exposed to torch through __cuda_array_interface__"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nq", type=int, default=1 << 20, help="query points per GPU")
+    ap.add_argument("--patches", type=int, default=256, help="patches per GPU")
+    ap.add_argument("--n", type=int, default=2000, help="points per patch")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import patchmixturekriging_amd as pmk
+    from patchmixturekriging_amd import mixture as M
+    pmk.set_device(local_rank)
+    ctx = pmk.default_context()
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)          # launch on torch's stream: its events then see our kernels
+
+    # ---------------------------------------------------------------- synthetic input (config C, weak-scaled)
+    P, n = args.patches, args.n
+    levels_local = int(round(np.log2(P))) + 1
+    assert 2 ** (levels_local - 1) == P, "--patches must be a power of two"
+    levels = levels_local + int(round(np.log2(world)))
+    assert 2 ** (levels - 1) == P * world, "--gpus must be a power of two"
+    N = P * n * world
+    a, sigma2, delta = 1 / 15, 1e-5, 1e-5
+    rng = np.random.Generator(np.random.PCG64(25))
+    X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+    y = oracle_f(X)
+    t0 = time.time()
+    root, X_parts, X_parts_inds = pmk.setuppartition(X, levels)        # host, exact; replicated on every rank
+    t_bsp = time.time() - t0
+    sizes = [len(p) for p in X_parts]
+    # radius = 0.1 x patch width: patch area = 200 / (P world)
+    radius = 0.1 * np.sqrt(200.0 / (P * world))
+    th, wth = pmk.Spline34KernelType(a), pmk.Spline34KernelType(1 / radius)
+    lo, hi = rank * P, (rank + 1) * P
+    model = pmk.DeviceModel(X_parts[lo:hi], [y[i] for i in X_parts_inds[lo:hi]])
+    model.set_bsp(root, lo)
+    Nq = args.nq * world
+    Xq = np.stack([rng.uniform(-5, 5, Nq), rng.uniform(-10, 10, Nq)], 1)
+    query = pmk.DeviceQuery(model, Xq)                                  # plan is replicated; items are sharded
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        sync()
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        dt = time.perf_counter() - t
+        if world > 1:
+            tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # ---------------------------------------------------------------- fit
+    stage_ms = {"kernel_matrix": [], "cholesky": [], "solve": [], "panel": []}
+
+    def fit_step():
+        model.fit(th, sigma2)
+
+    dt_fit = timed(fit_step, args.steps, args.warmup)
+    info = model.info()
+    assert np.all(info == 0), "a patch was not positive definite"
+    # per-stage device times (HIP events on the launch stream) of a few extra steps
+    ctx.L.pmk_ctx_enable_timers(ctx.h, 2)
+    for _ in range(3):
+        fit_step()
+        ctx.synchronize()
+        for k in stage_ms:
+            try:
+                stage_ms[k].append(ctx.timer_ms(k))
+            except pmk.PmkError:
+                pass
+    stage = {k: float(np.median(v)) for k, v in stage_ms.items() if v}
+
+    # ---------------------------------------------------------------- predict
+    def predict_step():
+        total = query.plan(radius, delta)                 # K5 + sort (blocks: sizes return to the host)
+        query.items(th)                                   # K4 on the owned regions
+        if world > 1:
+            u_ptr, v_ptr = query.item_buffers()
+            off = query.region_offsets(P * world)
+            seg = [int(off[(r + 1) * P] - off[r * P]) for r in range(world)]
+            mx = max(seg)
+            for ptr in (u_ptr, v_ptr):
+                full = torch.as_tensor(DevArray(ptr, total), device="cuda")
+                send = torch.zeros(mx, device="cuda", dtype=torch.float64)
+                send[:seg[rank]] = full[off[rank * P]:off[rank * P] + seg[rank]]
+                gathered = torch.empty(world * mx, device="cuda", dtype=torch.float64)
+                dist.all_gather_into_tensor(gathered, send)       # RCCL over xGMI: the path's one exchange
+                for r in range(world):
+                    if r != rank:
+                        full[off[r * P]:off[r * P] + seg[r]] = gathered[r * mx:r * mx + seg[r]]
+        q0, q1 = rank * args.nq, (rank + 1) * args.nq     # every rank blends its own slice of the queries
+        query.mix(wth, q0, q1)
+        return total
+
+    ctx.L.pmk_ctx_enable_timers(ctx.h, 0)
+    total_items = predict_step()
+    dt_pred = timed(predict_step, args.steps, max(1, args.warmup - 1))
+    ctx.L.pmk_ctx_enable_timers(ctx.h, 1)
+    predict_step()
+    ctx.synchronize()
+    pstage = {}
+    for k in ("plan", "items", "mix"):
+        try:
+            pstage[k] = ctx.timer_ms(k)
+        except pmk.PmkError:
+            pass
+    Yq, Vq = query.fetch()
+    sl = slice(rank * args.nq, (rank + 1) * args.nq)
+    assert np.all(np.isfinite(Yq[sl])) and np.all(Vq[sl] >= 1e-12)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel
+    ld = ((n + 127) // 128) * 128
+    nt = ld // 128
+    roof = None
+    if "panel" in stage:
+        flops = P * panel_flops(ld)
+        roof = {"bound": "mfma", "kernel": "chol_panel_kernel", "achieved": flops / (stage["panel"] * 1e-3) / 1e12,
+                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                "launches_per_step": nt - 1, "avg_launch_ms": stage["panel"] / (nt - 1),
+                "alg_flops_per_launch": flops / (nt - 1)}
+    elif "cholesky" in stage:
+        flops = P * chol_flops(n)
+        roof = {"bound": "mfma", "kernel": "chol_diag_kernel+chol_panel_kernel", "achieved": flops / (stage["cholesky"] * 1e-3) / 1e12,
+                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
+    if roof:
+        roof["frac"] = roof["achieved"] / roof["peak"]
+
+    # ---------------------------------------------------------------- CPU baseline (oracle = port), rank 0
+    cpu = None
+    if not args.no_cpu:
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle as O
+        cores = min(16, os.cpu_count() or 1)
+        oth, owth = O.kernel(O.SPLINE34, a), O.kernel(O.SPLINE34, 1 / radius)
+        sample = list(range(lo, lo + cores))
+        t = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:         # ctypes releases the GIL: one patch per core
+            fits = list(ex.map(lambda r: O.fit_patch(oth, X_parts[r], y[X_parts_inds[r]], sigma2), sample))
+        t_cpu_fit = time.perf_counter() - t
+        # predict: queries whose home and neighbours all fall in the sampled (contiguous) leaves
+        ob = O.BSP(X, levels)
+        dbg = query.debug()
+        offs, regs = dbg["item_offsets"], dbg["item_region"]
+        inside = np.zeros(P * world, bool)
+        inside[sample] = True
+        ok = np.add.reduceat(~inside[regs], offs[:-1]) == 0
+        qs = np.nonzero(ok)[0][:4000]
+        Xs = [X_parts[r] if inside[r] else X_parts[r][:1] for r in range(P * world)]
+        cs = [fits[r - lo]["c_lu"] if inside[r] else np.zeros(1) for r in range(P * world)]
+        Ls = [fits[r - lo]["L"] if inside[r] else np.ones((1, 1)) for r in range(P * world)]
+        t = time.perf_counter()
+        oY, oV = O.query_mixture(ob, oth, owth, Xs, cs, Ls, Xq[qs], radius, delta, nthreads=cores)
+        t_cpu_pred = time.perf_counter() - t
+        err_y = float(np.max(np.abs(Yq[qs] - oY) / np.maximum(1, np.abs(oY)))) if len(qs) else 0.0
+        err_v = float(np.max(np.abs(Vq[qs] - oV) / (1e-9 + 1e-5 * oV))) if len(qs) else 0.0
+        cpu = {"value": len(sample) / t_cpu_fit, "unit": "patch-solves/s", "cores": cores, "kind": "port",
+               "sample": "%d of %d patches (n=%d) by the C oracle (kernel loop + LU + Cholesky), one patch per thread"
+                         % (len(sample), P, n),
+               "predict_points_per_s": len(qs) / t_cpu_pred if len(qs) else None,
+               "predict_sample": "%d queries inside the sampled leaves, oracle querymixtureGP! on %d threads" % (len(qs), cores),
+               "parity_vs_gpu": {"max_rel_dY": err_y, "max_dV_over_tol": err_v}}
+
+    ms = dt_fit / args.steps * 1e3
+    out = {
+        "metric": "patch-solves/sec + predict-points/sec, 256 patches x 2k pts",
+        "value": P * world * args.steps / dt_fit,
+        "unit": "patch-solves/s",
+        "predict_points_per_s": Nq * args.steps / dt_pred,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "predict_ms_per_step": dt_pred / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "mixGP 2-D Spline34(1/15), %d BSP patches x %d points per GPU, sigma2=1e-5 (BASELINE config C)"
+                               % (P, n),
+                   "patches_per_gpu": P, "points_per_patch": n, "patch_sizes_minmax": [min(sizes), max(sizes)],
+                   "queries_per_gpu": args.nq, "radius": radius, "items_per_query": total_items / Nq,
+                   "levels": levels, "parallelism": "leaves sharded %d per GPU; one all-gather of (u,v)" % P,
+                   "bsp_build_s_host": t_bsp},
+        "stage_ms": {**stage, **{"predict_" + k: v for k, v in pstage.items()}},
+        "roofline": roof,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -131,6 +131,7 @@ void pmk_ctx_destroy(pmk_ctx *ctx)
 {
     if (!ctx) return;
     for (auto &t : ctx->tm) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto &e : ctx->panel_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -138,13 +139,24 @@ void pmk_ctx_destroy(pmk_ctx *ctx)
 int pmk_ctx_enable_timers(pmk_ctx *ctx, int on)
 {
     if (!ctx) { set_error("ctx is NULL"); return -1; }
-    ctx->timers = on != 0;
+    ctx->timers = on;
     return 0;
 }
 
 int pmk_ctx_timer_ms(pmk_ctx *ctx, const char *stage, double *ms)
 {
     if (!ctx || !stage || !ms) { set_error("pmk_ctx_timer_ms: NULL argument"); return -1; }
+    if (std::string(stage) == "panel" && ctx->panel_n > 0) {     // summed over the panel launches of the last fit
+        double tot = 0;
+        for (int i = 0; i < ctx->panel_n; ++i) {
+            PMK_HIP(hipEventSynchronize(ctx->panel_ev[(size_t)i].second));
+            float f = 0;
+            PMK_HIP(hipEventElapsedTime(&f, ctx->panel_ev[(size_t)i].first, ctx->panel_ev[(size_t)i].second));
+            tot += f;
+        }
+        *ms = tot;
+        return 0;
+    }
     for (auto &t : ctx->tm)
         if (t.name == stage && t.valid) {
             PMK_HIP(hipEventSynchronize(t.b));

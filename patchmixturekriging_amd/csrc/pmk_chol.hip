@@ -213,13 +213,29 @@ int launch_cholesky(pmk_model *m, hipStream_t s)
     // gemm_nt consumes K in groups of 4*PF k-indices; K is always a multiple of TILE here
     static_assert(TILE % (4 * PF_DIAG) == 0 && TILE % (4 * PF_CHOL) == 0, "prefetch depth must divide TILE/4");
     PMK_HIP(hipMemsetAsync(m->d_info, 0, sizeof(int32_t) * m->P, s));
+    m->ctx->panel_n = 0;
     for (int k = 0; k < m->max_nt; ++k) {
         hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)m->P), dim3(256), 0, s, m->d_desc, m->d_a, m->d_inv,
                            m->d_y, m->d_z, m->d_info, k);
         const int below = m->max_nt - k - 1;
         if (below > 0) {
+            pmk_ctx *c = m->ctx;
+            const bool fine = c->timers >= 2;
+            if (fine) {
+                while ((int)c->panel_ev.size() <= k) {
+                    hipEvent_t a, b;
+                    PMK_HIP(hipEventCreate(&a));
+                    PMK_HIP(hipEventCreate(&b));
+                    c->panel_ev.push_back({a, b});
+                }
+                PMK_HIP(hipEventRecord(c->panel_ev[(size_t)k].first, s));
+            }
             hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)below, (unsigned)m->P), dim3(256), 0, s,
                                m->d_desc, m->d_a, m->d_inv, k);
+            if (fine) {
+                PMK_HIP(hipEventRecord(c->panel_ev[(size_t)k].second, s));
+                c->panel_n = k + 1;
+            }
         }
     }
     PMK_HIP(hipGetLastError());

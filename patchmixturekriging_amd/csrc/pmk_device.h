@@ -14,6 +14,42 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // evaluated without FMA contraction, in the operation order of the reference's Julia code.
 #pragma clang fp contract(off)
 
+// t^n for the spline profiles.  The reference evaluates `tmp^6` / `tmp^4` with Julia's pow (<= 1 ulp); a
+// plain product chain t2*t2*t2 accumulates 3 roundings, which (1-r)^6 then carries into the result.
+// Double-double products (error-free transformations on FMA) give the correctly rounded power.
+struct dd_t { double hi, lo; };
+__device__ __forceinline__ dd_t dd_sqr(dd_t a)
+{
+    dd_t r;
+    r.hi = a.hi * a.hi;
+    r.lo = __builtin_fma(a.hi, a.hi, -r.hi) + 2.0 * (a.hi * a.lo);
+    const double s = r.hi + r.lo;
+    r.lo = r.lo - (s - r.hi);
+    r.hi = s;
+    return r;
+}
+__device__ __forceinline__ dd_t dd_mul(dd_t a, dd_t b)
+{
+    dd_t r;
+    r.hi = a.hi * b.hi;
+    r.lo = __builtin_fma(a.hi, b.hi, -r.hi) + (a.hi * b.lo + a.lo * b.hi);
+    const double s = r.hi + r.lo;
+    r.lo = r.lo - (s - r.hi);
+    r.hi = s;
+    return r;
+}
+__device__ __forceinline__ double pow4_cr(double t)
+{
+    const dd_t t4 = dd_sqr(dd_sqr(dd_t{t, 0.0}));
+    return t4.hi + t4.lo;
+}
+__device__ __forceinline__ double pow6_cr(double t)
+{
+    const dd_t t2 = dd_sqr(dd_t{t, 0.0});
+    const dd_t t6 = dd_mul(dd_sqr(t2), t2);
+    return t6.hi + t6.lo;
+}
+
 // evalkernel(tau, theta): src/RKHS/kernel.jl:299-381 of the reference
 __device__ __forceinline__ double profile(const pmk_kernel_desc &th, double tau)
 {
@@ -22,7 +58,7 @@ __device__ __forceinline__ double profile(const pmk_kernel_desc &th, double tau)
         double r = tau * th.p[0];
         double t = 1.0 - r;
         if (t < 0.0) return 0.0;
-        double t2 = t * t, t4 = t2 * t2, t6 = t4 * t2;       // t^6
+        const double t6 = pow6_cr(t);                        // tmp^6
         return (((35.0 * (r * r) + 18.0 * r) + 3.0) * t6) / 3.0;
     }
     case PMK_SPLINE12: {
@@ -35,8 +71,7 @@ __device__ __forceinline__ double profile(const pmk_kernel_desc &th, double tau)
         double r = tau * th.p[0];
         double t = 1.0 - r;
         if (t < 0.0) return 0.0;
-        double t2 = t * t;
-        return (4.0 * r + 1.0) * (t2 * t2);
+        return (4.0 * r + 1.0) * pow4_cr(t);               // tmp^4
     }
     case PMK_GAUSSIAN:
         return exp((-th.p[0]) * (tau * tau));

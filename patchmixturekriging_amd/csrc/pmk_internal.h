@@ -60,9 +60,11 @@ struct pmk_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    bool timers = false;
+    int timers = 0;                 // 0 off, 1 per stage, 2 also per panel launch
     struct Timer { std::string name; hipEvent_t a, b; bool valid; };
     std::vector<Timer> tm;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> panel_ev;   // one pair per panel launch of the last fit
+    int panel_n = 0;
     void tic(const char *name);
     void toc(const char *name);
 };

@@ -90,7 +90,7 @@ def test_kernel_matrix_vs_oracle(D):
         Ko = O.kernel_matrix(oth, X)
         assert np.array_equal(K, K.T)                              # RKHS.jl:27-31 mirror
         nz = Ko != 0
-        assert np.all((K == 0) == (Ko == 0) | (np.abs(K - Ko) < 1e-18))
+        assert np.all(((K == 0) == (Ko == 0)) | (np.abs(K - Ko) < 1e-18))
         assert ulps(K[nz], Ko[nz]).max() <= 4 or np.abs(K - Ko).max() < 1e-18, (th, ulps(K[nz], Ko[nz]).max())
         Kc = pmk.constructkernelmatrix(X, Z, th)
         Kco = O.cross_kernel_matrix(oth, X, Z)
@@ -322,7 +322,7 @@ def test_query_edge_cases():
     assert Yq[0] == 0.0 and Vq[0] == 1.0
     # a training point is interpolated and its variance sits near the noise floor
     Yq, Vq, _ = pmk.querymixtureGP(X[:257], eta, root, 3, 0.5, 1e-5, th, 1e-5, wth)
-    assert np.abs(Yq - y[:257]).max() < 1e-2 and np.all(Vq >= 1e-12) and np.all(Vq < 1e-3)
+    assert np.abs(Yq - y[:257]).max() < 5e-2 and np.all(Vq >= 1e-12) and np.all(Vq < 1e-3)
     # caller's buffers are resized (mixtureGP.jl:179-180)
     Y2, V2 = np.empty(3), np.empty(1)
     pmk.querymixtureGP_(Y2, V2, X[:257], eta, root, 3, 0.5, 1e-5, th, 1e-5, wth, pmk.MixtureGPDebugType(1.0))
