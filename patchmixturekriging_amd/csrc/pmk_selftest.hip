@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double *sink)
     double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = mfma64(a, b, acc[i]);
+        for (int i = 0; i < 16; ++i)   // inline asm: the builtin form makes hipcc shuttle accumulators VGPR<->AGPR
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
     }
     double s = 0.0;
 #pragma unroll
