@@ -47,6 +47,7 @@ def panel_flops(ld, tile=128):
     for k in range(nt - 1):
         rows = ld - (k + 1) * tile
         f += 2.0 * rows * tile * (tile * k) + rows * tile * tile
+        f += tile * tile * (tile * k)        # look-ahead workgroup: symmetric update of the next diagonal tile
     return f
 
 

@@ -128,8 +128,8 @@ int  pmk_model_info(pmk_model *m, int32_t *info);
 int  pmk_model_set_targets(pmk_model *m, const double *const *y);
 enum { PMK_GET_C = 0, PMK_GET_L = 1, PMK_GET_K = 2, PMK_GET_LINV_DIAG = 3 };
 /* pull c_set[r] (n), L_set[r] (n x n lower, strict upper zero), U_set[r] (n x n, K without
- * noise, rebuilt on demand), or the inverted 128x128 diagonal blocks (ceil(n/128) blocks,
- * 128 x 128 each, for tests) */
+ * noise, rebuilt on demand), or the negated inverses of the 32 x 32 diagonal blocks of L
+ * (4 ceil(n/128) blocks, 32 x 32 column-major each; the TRSM operands, for tests) */
 int  pmk_model_get(pmk_model *m, int64_t patch, int what, double *out, int64_t ld);
 int64_t pmk_model_num_patches(const pmk_model *m);
 void pmk_model_destroy(pmk_model *m);

@@ -90,7 +90,7 @@ SIGNATURES = {
     "pmk_query_mean": (C.c_int, [_vp, _kp, C.c_int, C.c_int64, _dp, _dp, C.c_int64, _dp, _dp]),
     # include/pmk_test.h
     "pmk_selftest_gemm": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
-    "pmk_selftest_trisolve": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "pmk_selftest_trisolve": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "pmk_selftest_mfma_peak": (C.c_int, [_vp, _dp]),
 }
 

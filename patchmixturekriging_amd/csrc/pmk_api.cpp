@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -55,13 +56,14 @@ static void dev_free(T *&p)
     p = nullptr;
 }
 
-// point-major host points (D x n) -> SoA rows of length ld, zero padded
+// point-major host points (D x n) -> SoA rows of length ld.  Padding entries are 1e300: their distance
+// to any real point overflows to +inf, so a compactly supported profile evaluates to exactly 0 there.
 static void pack_soa(int D, int64_t n, int64_t ld, const double *X, double *out)
 {
     for (int d = 0; d < D; ++d) {
         double *row = out + (int64_t)d * ld;
         for (int64_t i = 0; i < n; ++i) row[i] = X[i * D + d];
-        for (int64_t i = n; i < ld; ++i) row[i] = 0.0;
+        for (int64_t i = n; i < ld; ++i) row[i] = 1e300;
     }
 }
 
@@ -109,6 +111,7 @@ int pmk_ctx_create(int device, pmk_ctx **out)
     c->device = device;
     PMK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    if (const char *e = getenv("PMK_FIT_GROUPS")) c->fit_groups = std::max(1, atoi(e));
     *out = c;
     return 0;
 }
@@ -132,6 +135,9 @@ void pmk_ctx_destroy(pmk_ctx *ctx)
     if (!ctx) return;
     for (auto &t : ctx->tm) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto &e : ctx->panel_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &st : ctx->aux) (void)hipStreamDestroy(st);
+    for (auto &ev : ctx->aux_done) (void)hipEventDestroy(ev);
+    if (ctx->fork) (void)hipEventDestroy(ctx->fork);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -348,7 +354,7 @@ int pmk_model_create(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const dou
         a += (int64_t)d.ld * d.ld;
         xo += (int64_t)d.ld * D;
         yo += d.ld;
-        io += (int64_t)d.nt * TILE * TILE;
+        io += (int64_t)d.nt * 4 * 32 * 32;
         m->max_nt = std::max(m->max_nt, (int)d.nt);
     }
     m->tot_a = a; m->tot_x = xo; m->tot_y = yo; m->tot_inv = io;
@@ -400,17 +406,43 @@ int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)
     m->th = *th;
     m->sigma2 = sigma2;
     int rc;
-    c->tic("fit");
-    c->tic("kernel_matrix");
-    if ((rc = launch_kernel_matrix_slabs(m, *th, sigma2, c->stream))) return rc;
-    c->toc("kernel_matrix");
-    c->tic("cholesky");
-    if ((rc = launch_cholesky(m, c->stream))) return rc;
-    c->toc("cholesky");
-    c->tic("solve");
-    if ((rc = launch_backsolve(m, c->stream))) return rc;
-    c->toc("solve");
-    c->toc("fit");
+    const int G = (int)std::min<int64_t>(c->fit_groups, m->P);
+    if (c->timers || G <= 1) {
+        // one stream, stage by stage (the per-stage timers bracket whole stages)
+        c->tic("fit");
+        c->tic("kernel_matrix");
+        if ((rc = launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P))) return rc;
+        c->toc("kernel_matrix");
+        c->tic("cholesky");
+        if ((rc = launch_cholesky(m, c->stream, 0, m->P))) return rc;
+        c->toc("cholesky");
+        c->tic("solve");
+        if ((rc = launch_backsolve(m, c->stream, 0, m->P))) return rc;
+        c->toc("solve");
+        c->toc("fit");
+    } else {
+        // G independent sub-batches on side streams, forked from and joined back into the caller's stream
+        if (!c->fork) PMK_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+        while ((int)c->aux.size() < G) {
+            hipStream_t st;
+            hipEvent_t ev;
+            PMK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            PMK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->aux.push_back(st);
+            c->aux_done.push_back(ev);
+        }
+        PMK_HIP(hipEventRecord(c->fork, c->stream));
+        for (int g = 0; g < G; ++g) {
+            const int64_t p0 = m->P * g / G, p1 = m->P * (g + 1) / G;
+            hipStream_t st = c->aux[(size_t)g];
+            PMK_HIP(hipStreamWaitEvent(st, c->fork, 0));
+            if ((rc = launch_kernel_matrix_slabs(m, *th, sigma2, st, p0, p1 - p0))) return rc;
+            if ((rc = launch_cholesky(m, st, p0, p1 - p0))) return rc;
+            if ((rc = launch_backsolve(m, st, p0, p1 - p0))) return rc;
+            PMK_HIP(hipEventRecord(c->aux_done[(size_t)g], st));
+            PMK_HIP(hipStreamWaitEvent(c->stream, c->aux_done[(size_t)g], 0));
+        }
+    }
     m->fitted = true;
     return 0;
 }
@@ -471,7 +503,7 @@ int pmk_model_get(pmk_model *m, int64_t patch, int what, double *out, int64_t ld
         return rc;
     }
     case PMK_GET_LINV_DIAG:
-        PMK_HIP(hipMemcpyAsync(out, m->d_inv + d.ioff, sizeof(double) * (size_t)d.nt * TILE * TILE, hipMemcpyDeviceToHost,
+        PMK_HIP(hipMemcpyAsync(out, m->d_inv + d.ioff, sizeof(double) * (size_t)d.nt * 4 * 32 * 32, hipMemcpyDeviceToHost,
                                c->stream));
         PMK_HIP(hipStreamSynchronize(c->stream));
         return 0;

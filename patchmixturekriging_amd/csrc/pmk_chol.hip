@@ -3,12 +3,17 @@
 // (src/RKHS/mixtureGP.jl:106-112): one factorisation serves both.
 //
 // Step k of the factorisation (k = 0 .. nt-1), all patches at once, two launches:
-//   chol_diag_kernel  : one workgroup per patch.  T = A[kk] - L[k,0:k] L[k,0:k]^T on MFMA, unblocked
-//                       potrf of T in LDS -> L[kk]; inverse of L[kk] (used by every later TRSM as a
-//                       GEMM); forward-substitution piece z_k = L[kk]^-1 (y_k - L[k,0:k] z_0:k).
-//   chol_panel_kernel : grid over the block rows below.  T = A[i,k] - L[i,0:k] L[k,0:k]^T on MFMA
-//                       (the contraction the north star prices), then L[i,k] = T L[kk]^-T as a second
-//                       MFMA product with the accumulator tile reused in registers as the B operand.
+//   chol_diag_kernel  : one workgroup per patch.  Applies the last block column to the diagonal tile
+//                       (T = A[kk] - L[k,k-1] L[k,k-1]^T, MFMA), factors T in LDS with a 32-wide blocked
+//                       potrf, stores L[kk] and the negated inverses of its four 32 x 32 diagonal
+//                       blocks (every later TRSM is MFMA block substitution with them), and advances the
+//                       forward solve: z_k = L[kk]^-1 (y_k - L[k,0:k] z_0:k).
+//   chol_panel_kernel : grid over the block rows below + one "look-ahead" workgroup per patch.
+//                       Block rows: T = A[i,k] - L[i,0:k] L[k,0:k]^T on MFMA (the contraction the north
+//                       star prices), then L[i,k] = T L[kk]^-T by in-register block substitution.
+//                       Look-ahead workgroup: applies block columns 0..k-1 to the NEXT diagonal tile
+//                       (A[k+1,k+1] -= L[k+1,0:k] L[k+1,0:k]^T) and to the next forward-solve piece, so
+//                       the serial diagonal kernel only ever sees one block column of GEMM.
 // The slab is read once per block column (left-looking): reads only, no trailing-matrix
 // read-modify-write.  chol_backsolve_kernel then gives c = L^-T z.
 #include "pmk_mfma.h"
@@ -18,32 +23,50 @@ namespace pmk {
 constexpr int LDT = TILE + 1;   // LDS leading dimension of the diagonal tile (row access conflict-free)
 constexpr int PF_CHOL = 4;      // operand prefetch depth (k-steps) of the panel GEMM; must divide TILE/4
 constexpr int PF_DIAG = 4;
+constexpr int SB = 32;          // sub-block of the in-LDS potrf and of the TRSM block substitution
+
+// element (i, c) of the negated inverse of diagonal sub-block s is parked in the unused upper-right
+// quadrant of the LDS tile: rows [32 (s&1), +32) x columns [64 + 32 (s>>1), +32)
+__device__ __forceinline__ int ninv_lds(int s, int i, int c) { return (32 * (s & 1) + i) + (64 + 32 * (s >> 1) + c) * LDT; }
+
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
 
 // ---------------------------------------------------------------------------------------------
-// diagonal block: GEMM update + potrf + inverse + forward-solve piece
+// diagonal block
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restrict__ descs, double *__restrict__ A,
-                                                        double *__restrict__ inv, const double *__restrict__ y,
-                                                        double *__restrict__ z, int32_t *__restrict__ info, int k)
+                                                        double *__restrict__ ninv, const double *__restrict__ y,
+                                                        const double *__restrict__ ytmp, double *__restrict__ z,
+                                                        int32_t *__restrict__ info, int k)
 {
     const PatchDesc pd = descs[blockIdx.x];
     if (k >= pd.nt) return;
     __shared__ double T[TILE * LDT];
-    __shared__ double dinv[TILE];
     __shared__ double rhs[2 * TILE];
+    __shared__ int s_bad;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = wave >> 1, g = wave & 1;          // 64-row half, 64-column half of the tile
     double *S = A + pd.aoff;
     const int64_t ld = pd.ld;
-    const int K = k * TILE;
-    const int64_t r0 = (int64_t)k * TILE + 64 * h, c0 = (int64_t)k * TILE + 64 * g;
+    const int64_t d0 = (int64_t)k * TILE;
+    double *Akk = S + d0 + d0 * ld;
+    if (tid == 0) s_bad = 0;
 
-    // ---- T = A[kk] - L[k,0:k] L[k,0:k]^T  (lower 64x64 sub-tiles only)
+    // ---- T = A[kk] - L[k,k-1] L[k,k-1]^T   (older block columns were applied by the look-ahead
+    //      workgroup of the previous panel launch); lower 64 x 64 sub-tiles only
     if (!(h == 0 && g == 1)) {
         WaveTile<2, 2> acc;
         acc.zero();
-        if (K > 0) gemm_nt<2, 2, PF_DIAG>(acc, S + c0, ld, S + r0, ld, K, lane);
+        if (k > 0) {
+            const double *Lk = S + d0 + (d0 - TILE) * ld;      // L[k, k-1]: 128 x 128
+            gemm_nt<2, 2, PF_DIAG>(acc, Lk + 64 * g, ld, Lk + 64 * h, ld, TILE, lane);
+        }
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
@@ -52,94 +75,200 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
                 for (int pj = 0; pj < 2; ++pj) {
                     const int cl = 64 * g + 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * q) + (fi & 1);
                     const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
-                    const double2_t a =
-                        *reinterpret_cast<const double2_t *>(S + (int64_t)k * TILE + rl + ((int64_t)k * TILE + cl) * ld);
+                    const double2_t a = *reinterpret_cast<const double2_t *>(Akk + rl + (int64_t)cl * ld);
                     T[rl + cl * LDT] = a[0] - acc.f[fi][2 * pj][q];
                     T[rl + 1 + cl * LDT] = a[1] - acc.f[fi][2 * pj + 1][q];
                 }
     }
-    // ---- forward-substitution partial sums: rhs = L[k,0:k] z_0:k  (two column halves)
+    // ---- forward-solve right-hand side: y_k - L[k,0:k-1] z (look-ahead) - L[k,k-1] z_{k-1}
     {
         const int row = tid & 127, half = tid >> 7;
         double s = 0.0;
-        const double *Lr = S + (int64_t)k * TILE + row;
-        const double *zz = z + pd.yoff;
-        const int cbeg = half * (K / 2), cend = cbeg + K / 2;
-        for (int c = cbeg; c < cend; ++c) s += Lr[(int64_t)c * ld] * zz[c];
+        if (k > 0) {
+            const double *Lr = S + d0 + row + (d0 - TILE + 64 * half) * ld;
+            const double *zz = z + pd.yoff + d0 - TILE + 64 * half;
+            for (int c = 0; c < 64; ++c) s += Lr[(int64_t)c * ld] * zz[c];
+        }
         rhs[tid] = s;
     }
     __syncthreads();
+    if (tid < TILE) {
+        const double base = (k == 0) ? y[pd.yoff + tid] : ytmp[pd.yoff + d0 + tid];
+        rhs[tid] = base - (rhs[tid] + rhs[tid + TILE]);
+    }
 
-    // ---- unblocked right-looking potrf on the lower triangle of T
-    int bad = 0;
-    for (int j = 0; j < TILE; ++j) {
-        double d = T[j + j * LDT];
-        if (!(d > 0.0)) {          // not positive definite (or NaN): record the leading minor, keep going
-            if (!bad) bad = k * TILE + j + 1;
-            d = 1.0;
+    // ---- potrf of T in LDS, 32 columns at a time
+    for (int o = 0; o < TILE; o += SB) {
+        // (a) unblocked potrf of the 32 x 32 diagonal sub-block by the first 32 lanes of wave 0: lane i keeps
+        //     row i in registers, columns are broadcast with v_readlane (no LDS round trips in the chain)
+        if (wave == 0 && lane < SB) {
+            double row[SB];
+#pragma unroll
+            for (int l = 0; l < SB; ++l) row[l] = T[(o + lane) + (o + l) * LDT];
+#pragma unroll
+            for (int c = 0; c < SB; ++c) {
+                double d = readlane_f64(row[c], c);
+                if (!(d > 0.0)) {                         // not positive definite (or NaN): record, keep going
+                    if (lane == 0 && s_bad == 0) s_bad = k * TILE + o + c + 1;
+                    d = 1.0;
+                }
+                const double sq = sqrt(d);
+                row[c] = (lane == c) ? sq : row[c] / sq;
+#pragma unroll
+                for (int cc = c + 1; cc < SB; ++cc) row[cc] -= row[c] * readlane_f64(row[c], cc);
+            }
+#pragma unroll
+            for (int l = 0; l < SB; ++l)
+                if (l <= lane) T[(o + lane) + (o + l) * LDT] = row[l];
         }
-        const double s = sqrt(d);
         __syncthreads();
-        if (tid == j) T[j + j * LDT] = s;
-        if (tid > j && tid < TILE) T[tid + j * LDT] = T[tid + j * LDT] / s;
+        // (b) rows below: X = P D^-T, one thread per row, the row in registers;
+        //     wave 3 meanwhile inverts D (one thread per column of D^-1) and parks -D^-1
+        const int nbelow = TILE - o - SB;
+        if (tid < nbelow) {
+            const int r = o + SB + tid;
+            double p[SB];
+#pragma unroll
+            for (int l = 0; l < SB; ++l) p[l] = T[r + (o + l) * LDT];
+#pragma unroll
+            for (int jj = 0; jj < SB; ++jj) {
+                double s = p[jj];
+#pragma unroll
+                for (int l = 0; l < jj; ++l) s -= p[l] * T[(o + jj) + (o + l) * LDT];
+                p[jj] = s / T[(o + jj) + (o + jj) * LDT];
+            }
+#pragma unroll
+            for (int l = 0; l < SB; ++l) T[r + (o + l) * LDT] = p[l];
+        } else if (tid >= 192 && tid < 192 + SB) {
+            const int c = tid - 192;
+            double x[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int l = 0; l < i; ++l) s -= T[(o + i) + (o + l) * LDT] * x[l];
+                x[i] = s / T[(o + i) + (o + i) * LDT];
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) T[ninv_lds(o / SB, i, c)] = -x[i];
+        }
         __syncthreads();
-        const int i = tid & 127;
-        if (i > j) {
-            const double lij = T[i + j * LDT];
-            for (int c = j + 1 + (tid >> 7); c <= i; c += 2) T[i + c * LDT] -= lij * T[c + j * LDT];
+        // (c) trailing update of the lower triangle: T[r][c] -= sum_l X[r][l] X[c][l]
+        if (nbelow > 0) {
+            const int tr = tid & 15, tc = tid >> 4;
+            const int b0 = o + SB;
+            for (int r = b0 + tr; r < TILE; r += 16) {
+                double pr[SB];
+#pragma unroll
+                for (int l = 0; l < SB; ++l) pr[l] = T[r + (o + l) * LDT];
+                for (int c = b0 + tc; c <= r; c += 16) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int l = 0; l < SB; ++l) s += pr[l] * T[c + (o + l) * LDT];
+                    T[r + c * LDT] -= s;
+                }
+            }
         }
         __syncthreads();
     }
-    if (bad && tid == 0 && info[blockIdx.x] == 0) info[blockIdx.x] = bad;
+    if (tid == 0 && s_bad && info[blockIdx.x] == 0) info[blockIdx.x] = s_bad;
 
-    // ---- L[kk] -> slab (lower; the strict upper part of the slab block is zeroed)
+    // ---- L[kk] -> slab (lower; the strict upper part of the slab block is zeroed); -D^-1 blocks -> global
     for (int e = tid; e < TILE * TILE; e += 256) {
         const int i = e & 127, c = e >> 7;
-        S[(int64_t)k * TILE + i + ((int64_t)k * TILE + c) * ld] = (i >= c) ? T[i + c * LDT] : 0.0;
+        Akk[i + (int64_t)c * ld] = (i >= c) ? T[i + c * LDT] : 0.0;
     }
-    // ---- inverse of L[kk], one column per thread; X^T is kept in the strict upper triangle of T
-    if (tid < TILE) {
-        const int c = tid;
-        const double xcc = 1.0 / T[c + c * LDT];
-        dinv[c] = xcc;
-        for (int i = c + 1; i < TILE; ++i) {
-            double s = T[i + c * LDT] * xcc;
-            for (int kk = c + 1; kk < i; ++kk) s += T[i + kk * LDT] * T[c + kk * LDT];
-            T[c + i * LDT] = -s / T[i + i * LDT];
+    double *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
+    for (int e = tid; e < 4 * SB * SB; e += 256) {
+        const int s = e >> 10, i = e & 31, c = (e >> 5) & 31;
+        Ni[e] = (i >= c) ? T[ninv_lds(s, i, c)] : 0.0;
+    }
+    // ---- z_k = L[kk]^-1 rhs by block forward substitution (threads 0..31 own one 32-row block at a time)
+    for (int s = 0; s < 4; ++s) {
+        if (tid < SB) {
+            const int r = SB * s + tid;
+            double v = rhs[r];
+            for (int c = 0; c < SB * s; ++c) v -= T[r + c * LDT] * rhs[TILE + c];
+            rhs[r] = v;
         }
+        __syncthreads();
+        if (tid < SB) {
+            double v = 0.0;
+            for (int c = 0; c < SB; ++c) v -= T[ninv_lds(s, tid, c)] * rhs[SB * s + c];    // D^-1 r = -(Ninv r)
+            rhs[TILE + SB * s + tid] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    double *Li = inv + pd.ioff + (int64_t)k * TILE * TILE;
-    for (int e = tid; e < TILE * TILE; e += 256) {
-        const int i = e & 127, c = e >> 7;
-        Li[e] = (i > c) ? T[c + i * LDT] : (i == c ? dinv[c] : 0.0);
-    }
-    // ---- z_k = L[kk]^-1 (y_k - rhs)
-    if (tid < TILE) rhs[tid] = y[pd.yoff + (int64_t)k * TILE + tid] - (rhs[tid] + rhs[tid + TILE]);
-    __syncthreads();
-    if (tid < TILE) {
-        const int i = tid;
-        double s = dinv[i] * rhs[i];
-        for (int c = 0; c < i; ++c) s += T[c + i * LDT] * rhs[c];
-        z[pd.yoff + (int64_t)k * TILE + i] = s;
-    }
+    if (tid < TILE) z[pd.yoff + d0 + tid] = rhs[TILE + tid];
 }
 
 // ---------------------------------------------------------------------------------------------
-// block column below the diagonal: MFMA update + in-register TRSM
-// workgroup = one 128-row tile = 4 waves x (32 rows x 128 columns); the waves are independent (no
-// LDS, no barrier) and two workgroups share a CU (2 waves per SIMD hide each other's load latency)
+// block column below the diagonal: MFMA update + in-register TRSM, plus the look-ahead workgroup
+// block-row workgroup = one 128-row tile = 4 waves x (32 rows x 128 columns); the waves are
+// independent (no LDS, no barrier) and two workgroups share a CU (2 waves per SIMD)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__restrict__ descs, double *__restrict__ A,
-                                                            const double *__restrict__ inv, int k)
+                                                            const double *__restrict__ ninv, const double *__restrict__ y,
+                                                            const double *__restrict__ z, double *__restrict__ ytmp, int k)
 {
     const PatchDesc pd = descs[blockIdx.y];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t r0 = (int64_t)(k + 1 + blockIdx.x) * TILE + 32 * wave;
-    if (r0 >= pd.ld) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *S = A + pd.aoff;
     const int64_t ld = pd.ld;
     const int64_t c0 = (int64_t)k * TILE;
+
+    if (blockIdx.x == gridDim.x - 1) {
+        // ---- look-ahead for diagonal tile k+1: block columns 0..k-1 (column k is being produced by
+        //      this very launch and is applied by the next diagonal kernel)
+        const int64_t t0 = c0 + TILE;
+        if (k + 1 >= pd.nt) return;
+        const int h = wave >> 1, g = wave & 1;
+        if (k > 0 && !(h == 0 && g == 1)) {
+            WaveTile<2, 2> acc;
+            acc.zero();
+            gemm_nt<2, 2, PF_DIAG>(acc, S + t0 + 64 * g, ld, S + t0 + 64 * h, ld, k * TILE, lane);
+            double *Att = S + t0 + t0 * ld;
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int pj = 0; pj < 2; ++pj) {
+                        const int cl = 64 * g + 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * q) + (fi & 1);
+                        const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
+                        double2_t *p = reinterpret_cast<double2_t *>(Att + rl + (int64_t)cl * ld);
+                        double2_t a = *p;
+                        a[0] -= acc.f[fi][2 * pj][q];
+                        a[1] -= acc.f[fi][2 * pj + 1][q];
+                        *p = a;
+                    }
+        }
+        if (h == 0 && g == 1) {
+            // the wave without a GEMM sub-tile does the forward-solve piece: two rows per lane
+            const double *Lr = S + t0 + 2 * lane;
+            const double *zz = z + pd.yoff;
+            double2_t s0 = {0.0, 0.0}, s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, s3 = {0.0, 0.0};
+            for (int c = 0; c < k * TILE; c += 4) {
+                const double2_t a0 = *reinterpret_cast<const double2_t *>(Lr + (int64_t)c * ld);
+                const double2_t a1 = *reinterpret_cast<const double2_t *>(Lr + (int64_t)(c + 1) * ld);
+                const double2_t a2 = *reinterpret_cast<const double2_t *>(Lr + (int64_t)(c + 2) * ld);
+                const double2_t a3 = *reinterpret_cast<const double2_t *>(Lr + (int64_t)(c + 3) * ld);
+                s0 += a0 * zz[c]; s1 += a1 * zz[c + 1]; s2 += a2 * zz[c + 2]; s3 += a3 * zz[c + 3];
+            }
+            const double2_t sum = (s0 + s1) + (s2 + s3);
+            const double2_t yy = *reinterpret_cast<const double2_t *>(y + pd.yoff + t0 + 2 * lane);
+            *reinterpret_cast<double2_t *>(ytmp + pd.yoff + t0 + 2 * lane) = yy - sum;
+        }
+        return;
+    }
+
+    // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per
+    // workgroup; the loads are in flight while the GEMM below runs
+    if ((int64_t)(k + 1 + blockIdx.x) * TILE >= pd.ld) return;      // whole workgroup: ld is a multiple of TILE
+    __shared__ double tri[TRI_LDS_DOUBLES];
+    stage_tri_operands(tri, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
+    __syncthreads();
+    const int64_t r0 = (int64_t)(k + 1 + blockIdx.x) * TILE + 32 * wave;
     double *out = S + r0 + 2 * (lane & 15) + (c0 + 2 * (lane >> 4)) * ld;   // element (fi = 0, q = 0)
 
     // acc starts as -A[rows, block column k]; the GEMM adds L[rows,0:k] L[k,0:k]^T, so acc = -T
@@ -154,72 +283,90 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
             acc.f[fi][1][q] = -a[1];
         }
     if (k > 0) gemm_nt<4, 1, PF_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
-    // -L[rows, k] = (-T) L[kk]^-T  :  out[c'][r] = sum_c Linv[c'][c] (-T)[c][r]
-    tri_solve_inplace<1>(acc, inv + pd.ioff + (int64_t)k * TILE * TILE, lane);
+    // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
+    tri_solve_inplace<1>(acc, tri, lane);
 #pragma unroll
     for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cl = 32 * (fi >> 1) + 8 * q + (fi & 1);
             double2_t o;
-            o[0] = -acc.f[fi][0][q];
-            o[1] = -acc.f[fi][1][q];
+            o[0] = acc.f[fi][0][q];
+            o[1] = acc.f[fi][1][q];
             *reinterpret_cast<double2_t *>(out + cl * ld) = o;
         }
 }
 
 // ---------------------------------------------------------------------------------------------
-// c = L^-T z, one workgroup per patch, block rows from the last to the first
+// c = L^-T z, one workgroup (16 waves) per patch, block rows from the last to the first
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_backsolve_kernel(const PatchDesc *__restrict__ descs,
-                                                             const double *__restrict__ A, const double *__restrict__ inv,
-                                                             const double *__restrict__ z, double *__restrict__ cvec)
+__global__ __launch_bounds__(1024) void chol_backsolve_kernel(const PatchDesc *__restrict__ descs,
+                                                              const double *__restrict__ A, const double *__restrict__ ninv,
+                                                              const double *__restrict__ z, double *__restrict__ cvec)
 {
     const PatchDesc pd = descs[blockIdx.x];
-    __shared__ double part[TILE];
-    __shared__ double r[TILE];
+    extern __shared__ double sm[];
+    double *cs = sm;                  // ld : the solution so far
+    double *r = sm + pd.ld;           // TILE
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *S = A + pd.aoff;
     const int64_t ld = pd.ld;
-    double *c = cvec + pd.yoff;
     for (int k = pd.nt - 1; k >= 0; --k) {
-        // part[col] = sum_{i >= (k+1)*TILE} L[i, col] c[i]   for the 128 columns of block k
-        const int64_t i0 = (int64_t)(k + 1) * TILE;
-        for (int cc = wave; cc < TILE; cc += 4) {
-            const double *col = S + ((int64_t)k * TILE + cc) * ld;
-            double s = 0.0;
-            for (int64_t i = i0 + lane; i < ld; i += 64) s += col[i] * c[i];
+        const int64_t d0 = (int64_t)k * TILE;
+        // r[col] = z_k[col] - sum_{i >= d0 + TILE} L[i, d0 + col] c[i]: one wave per column, coalesced rows
+        const int64_t i0 = d0 + TILE;
+        for (int cc = wave; cc < TILE; cc += 16) {
+            const double *col = S + (d0 + cc) * ld;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int64_t i = i0 + lane;
+            for (; i + 192 < ld; i += 256) {
+                s0 += col[i] * cs[i];
+                s1 += col[i + 64] * cs[i + 64];
+                s2 += col[i + 128] * cs[i + 128];
+                s3 += col[i + 192] * cs[i + 192];
+            }
+            for (; i < ld; i += 64) s0 += col[i] * cs[i];
+            double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) part[cc] = s;
+            if (lane == 0) r[cc] = z[pd.yoff + d0 + cc] - s;
         }
         __syncthreads();
-        if (tid < TILE) r[tid] = z[pd.yoff + (int64_t)k * TILE + tid] - part[tid];
-        __syncthreads();
-        if (tid < TILE) {
-            // c_k[col] = sum_{i >= col} Linv[i][col] r[i]
-            const double *Li = inv + pd.ioff + (int64_t)k * TILE * TILE + (int64_t)tid * TILE;
-            double s = 0.0;
-            for (int i = tid; i < TILE; ++i) s += Li[i] * r[i];
-            c[(int64_t)k * TILE + tid] = s;
+        // c_k = L[kk]^-T r by block backward substitution with the negated inverted 32 x 32 blocks
+        const double *Lkk = S + d0 + d0 * ld;
+        const double *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
+        for (int s = 3; s >= 0; --s) {
+            if (tid < SB) {
+                const int col = SB * s + tid;
+                double v = r[col];
+                for (int i = SB * (s + 1); i < TILE; ++i) v -= Lkk[i + (int64_t)col * ld] * cs[d0 + i];
+                r[col] = v;
+            }
+            __syncthreads();
+            if (tid < SB) {
+                double v = 0.0;
+                for (int i = tid; i < SB; ++i) v -= Ni[1024 * s + i + 32 * tid] * r[SB * s + i];   // D^-T r
+                cs[d0 + SB * s + tid] = v;
+            }
+            __syncthreads();
         }
-        __threadfence_block();
-        __syncthreads();
     }
+    for (int i = tid; i < pd.ld; i += 1024) cvec[pd.yoff + i] = cs[i];
 }
 
-int launch_cholesky(pmk_model *m, hipStream_t s)
+int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 {
     // gemm_nt consumes K in groups of 4*PF k-indices; K is always a multiple of TILE here
     static_assert(TILE % (4 * PF_DIAG) == 0 && TILE % (4 * PF_CHOL) == 0, "prefetch depth must divide TILE/4");
-    PMK_HIP(hipMemsetAsync(m->d_info, 0, sizeof(int32_t) * m->P, s));
-    m->ctx->panel_n = 0;
+    PMK_HIP(hipMemsetAsync(m->d_info + p0, 0, sizeof(int32_t) * np, s));
+    pmk_ctx *c = m->ctx;
+    c->panel_n = 0;
+    double *ytmp = m->d_c;      // the weight vector is free until the back substitution: scratch for y - L z
     for (int k = 0; k < m->max_nt; ++k) {
-        hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)m->P), dim3(256), 0, s, m->d_desc, m->d_a, m->d_inv,
-                           m->d_y, m->d_z, m->d_info, k);
+        hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)np), dim3(256), 0, s, m->d_desc + p0, m->d_a, m->d_inv,
+                           m->d_y, ytmp, m->d_z, m->d_info + p0, k);
         const int below = m->max_nt - k - 1;
         if (below > 0) {
-            pmk_ctx *c = m->ctx;
             const bool fine = c->timers >= 2;
             if (fine) {
                 while ((int)c->panel_ev.size() <= k) {
@@ -230,8 +377,9 @@ int launch_cholesky(pmk_model *m, hipStream_t s)
                 }
                 PMK_HIP(hipEventRecord(c->panel_ev[(size_t)k].first, s));
             }
-            hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)below, (unsigned)m->P), dim3(256), 0, s,
-                               m->d_desc, m->d_a, m->d_inv, k);
+            // grid.x = block rows below + 1 look-ahead workgroup
+            hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(below + 1), (unsigned)np), dim3(256), 0, s,
+                               m->d_desc + p0, m->d_a, m->d_inv, m->d_y, m->d_z, ytmp, k);
             if (fine) {
                 PMK_HIP(hipEventRecord(c->panel_ev[(size_t)k].second, s));
                 c->panel_n = k + 1;
@@ -242,9 +390,10 @@ int launch_cholesky(pmk_model *m, hipStream_t s)
     return 0;
 }
 
-int launch_backsolve(pmk_model *m, hipStream_t s)
+int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 {
-    hipLaunchKernelGGL(chol_backsolve_kernel, dim3((unsigned)m->P), dim3(256), 0, s, m->d_desc, m->d_a, m->d_inv,
+    const size_t lds = sizeof(double) * ((size_t)m->max_nt * TILE + TILE);
+    hipLaunchKernelGGL(chol_backsolve_kernel, dim3((unsigned)np), dim3(1024), lds, s, m->d_desc + p0, m->d_a, m->d_inv,
                        m->d_z, m->d_c);
     PMK_HIP(hipGetLastError());
     return 0;

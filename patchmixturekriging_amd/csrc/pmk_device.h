@@ -50,16 +50,34 @@ __device__ __forceinline__ double pow6_cr(double t)
     return t6.hi + t6.lo;
 }
 
-// evalkernel(tau, theta): src/RKHS/kernel.jl:299-381 of the reference
+// x / 3.0, correctly rounded, without the ~30-instruction IEEE division sequence: q = RN(x * RN(1/3)),
+// the residual r = x - 3 q is exact in an FMA, and RN(q + r * RN(1/3)) is the correctly rounded quotient
+// (Markstein's division-by-constant correction; 3 has no all-ones significand).
+__device__ __forceinline__ double div3_cr(double x)
+{
+    const double y = 1.0 / 3.0;
+    const double q = x * y;
+    const double r = __builtin_fma(-3.0, q, x);
+    return __builtin_fma(r, y, q);
+}
+
+// evalkernel(tau, theta): src/RKHS/kernel.jl:299-381 of the reference.
+// FAM != 0 fixes the family at compile time (the hot kernels are instantiated for Spline34 so the
+// unrolled tile loops carry one straight-line formula instead of the whole switch).
+template <int FAM = 0>
 __device__ __forceinline__ double profile(const pmk_kernel_desc &th, double tau)
 {
-    switch (th.family) {
+    switch (FAM ? FAM : th.family) {
     case PMK_SPLINE34: {
         double r = tau * th.p[0];
         double t = 1.0 - r;
-        if (t < 0.0) return 0.0;
+        // branch-free form of `if sign(tmp) < 0 return 0`: outside the support evaluate at r = 1, t = 0,
+        // which gives exactly +0.0 (selects, so the unrolled tile loops stay straight-line code)
+        const bool outside = t < 0.0;
+        r = outside ? 1.0 : r;
+        t = outside ? 0.0 : t;
         const double t6 = pow6_cr(t);                        // tmp^6
-        return (((35.0 * (r * r) + 18.0 * r) + 3.0) * t6) / 3.0;
+        return div3_cr(((35.0 * (r * r) + 18.0 * r) + 3.0) * t6);
     }
     case PMK_SPLINE12: {
         double r = tau * th.p[0];
@@ -139,16 +157,17 @@ __device__ __forceinline__ double bb_scalar(const pmk_kernel_desc &th, double x,
 // evalkernel(p, q, theta) with p, q in registers.  Stationary: tau = norm(p-q) as a sequential
 // sum of squares and one sqrt (kernel.jl:277-287); Brownian bridge: product over dimensions
 // (kernel.jl:196-206).
-template <int D>
+template <int D, int FAM = 0>
 __device__ __forceinline__ double kern_eval(const pmk_kernel_desc &th, const double *p, const double *q)
 {
-    if (th.family >= PMK_BB10) {
+    const int fam = FAM ? FAM : th.family;
+    if (fam >= PMK_BB10) {
         double out = bb_scalar(th, p[0], q[0]);
 #pragma unroll
         for (int d = 1; d < D; ++d) out = out * bb_scalar(th, p[d], q[d]);
         return out;
     }
-    if (th.family == PMK_MODSQEXP && D > 1) return __builtin_nan("");
+    if (fam == PMK_MODSQEXP && D > 1) return __builtin_nan("");
     double r0 = p[0] - q[0];
     double s = r0 * r0;
 #pragma unroll
@@ -156,7 +175,7 @@ __device__ __forceinline__ double kern_eval(const pmk_kernel_desc &th, const dou
         double r = p[d] - q[d];
         s = s + r * r;
     }
-    return profile(th, sqrt(s));
+    return profile<FAM>(th, sqrt(s));
 }
 
 // dot(u, x) as the reference's short ddot: sequential multiply-add, no FMA

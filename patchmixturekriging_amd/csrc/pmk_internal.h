@@ -36,7 +36,7 @@ struct PatchDesc {
     int64_t aoff;     // element offset of the ld x ld slab (K, then L in place)
     int64_t xoff;     // element offset of the SoA coordinates: x[d][ld]
     int64_t yoff;     // element offset into y / z / c (ld each)
-    int64_t ioff;     // element offset of the inverted diagonal blocks: nt x (TILE x TILE)
+    int64_t ioff;     // element offset of the negated inverted 32 x 32 diagonal blocks: nt x 4 x (32 x 32)
 };
 
 // A BSP tree in heap order (root 0, children 2i+1 / 2i+2); leaves numbered left to right.
@@ -65,6 +65,12 @@ struct pmk_ctx {
     std::vector<Timer> tm;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> panel_ev;   // one pair per panel launch of the last fit
     int panel_n = 0;
+    // the fit runs the patch batch as `fit_groups` independent sub-batches on side streams: the serial,
+    // latency-bound diagonal-block kernel of one group overlaps the MFMA-bound panel kernel of the others
+    int fit_groups = 1;     // measured on MI355X (profiles/r01_fit_groups.txt): 1-2 groups tie, more are slower
+    std::vector<hipStream_t> aux;
+    std::vector<hipEvent_t> aux_done;
+    hipEvent_t fork = nullptr;
     void tic(const char *name);
     void toc(const char *name);
 };
@@ -81,7 +87,7 @@ struct pmk_model {
     double *d_z = nullptr;              // L^-1 y
     double *d_c = nullptr;              // weights
     double *d_a = nullptr;              // slabs
-    double *d_inv = nullptr;            // inverted diagonal blocks
+    double *d_inv = nullptr;            // -(L[ss])^-1 for every 32 x 32 diagonal block of L
     int32_t *d_info = nullptr;          // per patch
     int64_t tot_a = 0, tot_x = 0, tot_y = 0, tot_inv = 0;
     bool fitted = false;
@@ -123,12 +129,13 @@ struct pmk_query {
 namespace pmk {
 
 // ---- launchers implemented in the .hip files (all enqueue on `s`) ----
-int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s);
+int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s,
+                               int64_t p0, int64_t np);
 int launch_kernel_matrix_dense(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
                                int64_t mcols, const double *d_zs, int64_t ldz, double *d_K, int64_t ldk,
                                bool symmetric, hipStream_t s);
-int launch_cholesky(pmk_model *m, hipStream_t s);
-int launch_backsolve(pmk_model *m, hipStream_t s);
+int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);
+int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);
 int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_plan_fill(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_sort_items(pmk_query *q, hipStream_t s);

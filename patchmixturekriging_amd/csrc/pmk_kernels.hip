@@ -14,7 +14,7 @@ namespace pmk {
 // 16-thread row group stores 512 contiguous bytes per column.  Padding rows/columns (index >= n) are
 // written as identity so the padded factorisation stays positive definite.
 // =============================================================================================
-template <int D>
+template <int D, int FAM>
 __global__ __launch_bounds__(256) void kmat_slab_kernel(const PatchDesc *__restrict__ descs, const double *__restrict__ x,
                                                         double *__restrict__ A, pmk_kernel_desc th, double sigma2)
 {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void kmat_slab_kernel(const PatchDesc *__restr
             const int i = i0 + a;
             double v;
             if (i < pd.n && j < pd.n) {
-                v = (i >= j) ? kern_eval<D>(th, xi[a], xj[b]) : kern_eval<D>(th, xj[b], xi[a]);
+                v = (i >= j) ? kern_eval<D, FAM>(th, xi[a], xj[b]) : kern_eval<D, FAM>(th, xj[b], xi[a]);
                 if (i == j) v = v + sigma2;
             } else {
                 v = (i == j) ? 1.0 : 0.0;
@@ -60,11 +60,14 @@ __global__ __launch_bounds__(256) void kmat_slab_kernel(const PatchDesc *__restr
 }
 
 template <int D>
-static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s)
+static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s, int64_t p0, int64_t np)
 {
     const int nt64 = m->max_nt * (TILE / 64);
-    dim3 grid((unsigned)(nt64 * (nt64 + 1) / 2), (unsigned)m->P);
-    hipLaunchKernelGGL(kmat_slab_kernel<D>, grid, dim3(256), 0, s, m->d_desc, m->d_x, m->d_a, th, sigma2);
+    dim3 grid((unsigned)(nt64 * (nt64 + 1) / 2), (unsigned)np);
+    if (th.family == PMK_SPLINE34)
+        hipLaunchKernelGGL((kmat_slab_kernel<D, PMK_SPLINE34>), grid, dim3(256), 0, s, m->d_desc + p0, m->d_x, m->d_a, th, sigma2);
+    else
+        hipLaunchKernelGGL((kmat_slab_kernel<D, 0>), grid, dim3(256), 0, s, m->d_desc + p0, m->d_x, m->d_a, th, sigma2);
     PMK_HIP(hipGetLastError());
     return 0;
 }
@@ -78,10 +81,11 @@ static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double s
     default: set_error("unsupported input dimension %d (1..%d)", (int)(D), MAX_D); return -2; \
     }
 
-int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s)
+int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s,
+                               int64_t p0, int64_t np)
 {
     int rc = 0;
-    PMK_DISPATCH_D(m->D, rc = launch_slab_D<DD>(m, th, sigma2, s));
+    PMK_DISPATCH_D(m->D, rc = launch_slab_D<DD>(m, th, sigma2, s, p0, np));
     return rc;
 }
 

@@ -76,44 +76,84 @@ __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const double *opI
     }
 }
 
-// In-register triangular solve with an inverted 128 x 128 diagonal block:
-//   t[I][J] <- sum_k Linv[I][k] * t[k][J],   I, k in [0,128)  (NPI = 4)
-// Linv: column-major 128 x 128, lower triangular with explicit zeros above the diagonal.
-// The accumulator registers of t are used directly as the MFMA B operand: register q of fragment
-// (pi, ei) holds k = 32 pi + 8 q + 2 (lane>>4) + ei, which is a legal k-step when the A operand is
-// gathered with the same k.  Output pair blocks are produced from the last to the first so the
-// update is in place.
-template <int NPJ>
-__device__ __forceinline__ void tri_solve_inplace(WaveTile<4, NPJ> &t, const double *Linv, int lane)
+// In-register triangular solve of a 128-row tile, by block forward substitution over its four
+// 32-row blocks:   t  <-  -L^-1 t     (t: 128 x NJ*16, rows = the I dimension)
+//   u_s = Ninv_s (t_s + sum_{j<s} L[s][j] u_j),   Ninv_s = -(L[s][s])^-1  (negated inverted 32 x 32 blocks)
+// The operands are staged in LDS by stage_tri_operands(): the six 32 x 32 blocks of L strictly below
+// the block diagonal (block (s, j) at index s(s-1)/2 + j) followed by the four Ninv blocks, each
+// column-major with leading dimension 32.  Reading them from global memory inside the dependent
+// stages exposed an L2 round trip per stage (a fixed ~30 us per block row of the panel launch).
+// Every product is an MFMA whose B operand is an accumulator register of t itself: register q of
+// fragment (pi, ei) holds row k = 32 pi + 8 q + 2 (lane>>4) + ei, a legal k-step once the A operand
+// is gathered with the same k.  The fragment pairing permutes rows only inside a 32-block, so the
+// block structure of L is preserved.
+constexpr int TRI_LDS_DOUBLES = 10 * 32 * 32;
+
+// cooperative copy by all `nthreads` threads of the workgroup; caller synchronises before and after.
+// L: factored diagonal tile (column-major, ldl); ninv: its 4 negated inverted diagonal blocks (global)
+__device__ __forceinline__ void stage_tri_operands(double *lds, const double *L, int64_t ldl, const double *ninv,
+                                                   int tid, int nthreads)
 {
+    // 16-byte pieces: 512 per block
+    for (int e = tid; e < 10 * 512; e += nthreads) {
+        const int b = e >> 9, w = e & 511;          // block, piece
+        const int i = 2 * (w & 15), c = w >> 4;     // rows i, i+1 of column c
+        double2_t v;
+        if (b < 6) {
+            const int s = (b >= 3) ? 3 : (b >= 1 ? 2 : 1);
+            const int j = b - s * (s - 1) / 2;
+            v = *reinterpret_cast<const double2_t *>(L + 32 * s + i + (int64_t)(32 * j + c) * ldl);
+        } else {
+            v = *reinterpret_cast<const double2_t *>(ninv + 1024 * (b - 6) + i + 32 * c);
+        }
+        *reinterpret_cast<double2_t *>(lds + 1024 * b + i + 32 * c) = v;
+    }
+}
+
+template <int NPJ>
+__device__ __forceinline__ void tri_solve_inplace(WaveTile<4, NPJ> &t, const double *lds, int lane)
+{
+    const double *base = lds + 2 * (lane & 15) + 32 * (2 * (lane >> 4));
 #pragma unroll
-    for (int pip = 3; pip >= 0; --pip) {
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int pj = 0; pj < s; ++pj) {
+            const double *blk = base + 1024 * (s * (s - 1) / 2 + pj);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double2_t a = *reinterpret_cast<const double2_t *>(blk + 32 * (8 * q + e));
+#pragma unroll
+                    for (int j = 0; j < 2 * NPJ; ++j) {
+                        t.f[2 * s + 0][j] = mfma64(a[0], t.f[2 * pj + e][j][q], t.f[2 * s + 0][j]);
+                        t.f[2 * s + 1][j] = mfma64(a[1], t.f[2 * pj + e][j][q], t.f[2 * s + 1][j]);
+                    }
+                }
+            }
+        }
         double4_t o[2][2 * NPJ];
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int j = 0; j < 2 * NPJ; ++j) o[e][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+        const double *blk = base + 1024 * (6 + s);
 #pragma unroll
-        for (int pi = 0; pi <= pip; ++pi) {
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int e = 0; e < 2; ++e) {
+                const double2_t a = *reinterpret_cast<const double2_t *>(blk + 32 * (8 * q + e));
 #pragma unroll
-                for (int ei = 0; ei < 2; ++ei) {
-                    const int kl = 32 * pi + 8 * q + 2 * (lane >> 4) + ei;
-                    const double2_t a =
-                        *reinterpret_cast<const double2_t *>(Linv + 32 * pip + 2 * (lane & 15) + kl * TILE);
-#pragma unroll
-                    for (int j = 0; j < 2 * NPJ; ++j) {
-                        o[0][j] = mfma64(a[0], t.f[2 * pi + ei][j][q], o[0][j]);
-                        o[1][j] = mfma64(a[1], t.f[2 * pi + ei][j][q], o[1][j]);
-                    }
+                for (int j = 0; j < 2 * NPJ; ++j) {
+                    o[0][j] = mfma64(a[0], t.f[2 * s + e][j][q], o[0][j]);
+                    o[1][j] = mfma64(a[1], t.f[2 * s + e][j][q], o[1][j]);
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < 2 * NPJ; ++j) {
-            t.f[2 * pip + 0][j] = o[0][j];
-            t.f[2 * pip + 1][j] = o[1][j];
+            t.f[2 * s + 0][j] = o[0][j];
+            t.f[2 * s + 1][j] = o[1][j];
         }
     }
 }

@@ -10,7 +10,7 @@
 //
 // Strip task, block row i:  acc(128 x 32) = Kq_i - sum_{j<i} L[i,j] V_j   (gemm_nt, V_j re-read from the
 // wave's strip in global memory, which is stored negated so the MFMA accumulates the subtraction)
-//                           V_i = Linv[ii] acc                            (tri_solve_inplace)
+//                           -V_i = -L[ii]^-1 acc                          (tri_solve_inplace: block substitution)
 #include "pmk_mfma.h"
 
 namespace pmk {
@@ -23,7 +23,7 @@ struct StripTask {
     int64_t first;     // first sorted item of the strip
 };
 
-template <int D>
+template <int D, int FAM>
 __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *__restrict__ descs,
                                                                const double *__restrict__ x, const double *__restrict__ A,
                                                                const double *__restrict__ inv, const double *__restrict__ cvec,
@@ -36,10 +36,11 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *V = strips + (int64_t)blockIdx.x * strip_stride + 32 * wave;   // this wave's 32 columns, ld = TQ
+    __shared__ double tri[TRI_LDS_DOUBLES];     // TRSM operands of the current block row (shared by the 4 waves)
 
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
         const StripTask tk = tasks[task];
-        if (32 * wave >= tk.count) continue;          // wave-uniform: nothing to do for this wave
+        const bool active = 32 * wave < tk.count;     // wave-uniform; idle waves still help stage operands
         const PatchDesc pd = descs[tk.region];
         const double *S = A + pd.aoff;
         const double *xs = x + pd.xoff;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
         for (int ej = 0; ej < 2; ++ej) {
             const int col = 32 * wave + 2 * (lane & 15) + ej;
             valid[ej] = col < tk.count;
-            pos[ej] = tk.first + (valid[ej] ? col : tk.count - 1);     // padding columns repeat the last item
+            pos[ej] = tk.first + (valid[ej] ? col : 0);                // padding columns repeat a valid item
             const int64_t qi = item_query[sorted_item[pos[ej]]];
 #pragma unroll
             for (int d = 0; d < D; ++d) q[ej][d] = xq[qi * D + d];
@@ -62,6 +63,11 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
         double mu[2] = {0.0, 0.0}, vs[2] = {0.0, 0.0};
 
         for (int i = 0; i < pd.nt; ++i) {
+            __syncthreads();                          // every wave is done with the previous block row's operands
+            stage_tri_operands(tri, S + (int64_t)i * TILE + (int64_t)i * TILE * ld, ld, inv + pd.ioff + (int64_t)i * 4096,
+                               threadIdx.x, 256);
+            __syncthreads();
+            if (!active) continue;
             WaveTile<4, 1> acc;
             // ---- Kq tile for block row i (query is the first kernel argument, mixtureGP.jl:304)
 #pragma unroll
@@ -73,10 +79,12 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
 #pragma unroll
                     for (int d = 0; d < D; ++d) xr[d] = xs[(int64_t)d * ld + row];
                     const double cw = cr[row];
-                    const bool inside = row < pd.n;
+                    // padding rows carry coordinates of 1e300 (pack_soa): a compactly supported profile is
+                    // exactly 0 there, so the Spline34 instantiation needs no bounds test in its unrolled tile
+                    const bool inside = (FAM == PMK_SPLINE34) || row < pd.n;
 #pragma unroll
                     for (int ej = 0; ej < 2; ++ej) {
-                        const double kv = inside ? kern_eval<D>(th, q[ej], xr) : 0.0;
+                        const double kv = inside ? kern_eval<D, FAM>(th, q[ej], xr) : 0.0;
                         acc.f[fi][ej][qq] = kv;
                         mu[ej] += kv * cw;
                     }
@@ -87,8 +95,8 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 gemm_nt<4, 1, PF_PRED>(acc, S + (int64_t)i * TILE, ld, V, TQ, i * TILE, lane);
             }
-            // ---- V_i = Linv[ii] acc
-            tri_solve_inplace<1>(acc, inv + pd.ioff + (int64_t)i * TILE * TILE, lane);
+            // ---- acc <- -V_i = -L[ii]^-1 acc   (block substitution; the strip wants -V anyway)
+            tri_solve_inplace<1>(acc, tri, lane);
 #pragma unroll
             for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
@@ -102,20 +110,20 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
                     for (int qq = 0; qq < 4; ++qq) {
                         const int row = i * TILE + 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * qq) + (fi & 1);
                         double2_t o;
-                        o[0] = -acc.f[fi][0][qq];
-                        o[1] = -acc.f[fi][1][qq];
+                        o[0] = acc.f[fi][0][qq];
+                        o[1] = acc.f[fi][1][qq];
                         *reinterpret_cast<double2_t *>(V + (int64_t)row * TQ + 2 * (lane & 15)) = o;
                     }
             }
         }
         // ---- reduce over the four lane groups that share a column, then write (u, v)
 #pragma unroll
-        for (int ej = 0; ej < 2; ++ej) {
+        for (int ej = 0; ej < 2 && active; ++ej) {
             double a = mu[ej], b = vs[ej];
             a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
             a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
             if ((lane >> 4) == 0 && valid[ej]) {
-                const double kself = kern_eval<D>(th, q[ej], q[ej]);
+                const double kself = kern_eval<D, FAM>(th, q[ej], q[ej]);
                 double var = kself - b;                               // mixtureGP.jl:312
                 var = var < 1e-12 ? 1e-12 : var;
                 u_out[pos[ej]] = a;
@@ -169,12 +177,18 @@ int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s)
     if (q->ntasks == 0) return 0;
     const int64_t stride = (int64_t)m->max_nt * TILE * TQ;
     const StripTask *d_tasks = reinterpret_cast<const StripTask *>(q->d_tasks);
+    const bool s34 = th.family == PMK_SPLINE34;
     switch (m->D) {
 #define PMK_CASE(DD)                                                                                                   \
     case DD:                                                                                                           \
-        hipLaunchKernelGGL(predict_strip_kernel<DD>, dim3((unsigned)q->strip_grid), dim3(256), 0, s, m->d_desc, m->d_x, \
-                           m->d_a, m->d_inv, m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item, q->d_item_query,        \
-                           q->d_xq, m->d_strip, stride, th, q->d_u, q->d_v);                                            \
+        if (s34)                                                                                                       \
+            hipLaunchKernelGGL((predict_strip_kernel<DD, PMK_SPLINE34>), dim3((unsigned)q->strip_grid), dim3(256), 0, s, \
+                               m->d_desc, m->d_x, m->d_a, m->d_inv, m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
+                               q->d_item_query, q->d_xq, m->d_strip, stride, th, q->d_u, q->d_v);                       \
+        else                                                                                                           \
+            hipLaunchKernelGGL((predict_strip_kernel<DD, 0>), dim3((unsigned)q->strip_grid), dim3(256), 0, s,           \
+                               m->d_desc, m->d_x, m->d_a, m->d_inv, m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
+                               q->d_item_query, q->d_xq, m->d_strip, stride, th, q->d_u, q->d_v);                       \
         break;
         PMK_CASE(1) PMK_CASE(2) PMK_CASE(3) PMK_CASE(4)
 #undef PMK_CASE

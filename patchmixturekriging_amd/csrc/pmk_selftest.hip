@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64) void selftest_gemm_kernel(int K, const double *
             }
 }
 
-__global__ __launch_bounds__(64) void selftest_trisolve_kernel(const double *Linv, const double *Tin, double *Tout)
+__global__ __launch_bounds__(64) void selftest_trisolve_kernel(const double *L, const double *ninv, const double *Tin, double *Tout)
 {
     const int lane = threadIdx.x;
     WaveTile<4, 1> t;
@@ -39,7 +39,10 @@ __global__ __launch_bounds__(64) void selftest_trisolve_kernel(const double *Lin
                 const int J = 32 * (fj >> 1) + 2 * (lane & 15) + (fj & 1);
                 t.f[fi][fj][q] = Tin[J + 32 * I];
             }
-    tri_solve_inplace<1>(t, Linv, lane);
+    __shared__ double tri[TRI_LDS_DOUBLES];
+    stage_tri_operands(tri, L, 128, ninv, lane, 64);
+    __syncthreads();
+    tri_solve_inplace<1>(t, tri, lane);
 #pragma unroll
     for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
@@ -94,21 +97,23 @@ int pmk_selftest_gemm(pmk_ctx *ctx, int K, const double *MI, const double *MJ, d
     return 0;
 }
 
-int pmk_selftest_trisolve(pmk_ctx *ctx, const double *Linv, const double *T_in, double *T_out)
+int pmk_selftest_trisolve(pmk_ctx *ctx, const double *L, const double *ninv, const double *T_in, double *T_out)
 {
-    if (!ctx || !Linv || !T_in || !T_out) { set_error("pmk_selftest_trisolve: bad argument"); return -1; }
+    if (!ctx || !L || !ninv || !T_in || !T_out) { set_error("pmk_selftest_trisolve: bad argument"); return -1; }
     PMK_HIP(hipSetDevice(ctx->device));
-    double *dL, *dI, *dO;
+    double *dL, *dN, *dI, *dO;
     PMK_HIP(hipMalloc((void **)&dL, sizeof(double) * 128 * 128));
+    PMK_HIP(hipMalloc((void **)&dN, sizeof(double) * 4096));
+    PMK_HIP(hipMemcpy(dN, ninv, sizeof(double) * 4096, hipMemcpyHostToDevice));
     PMK_HIP(hipMalloc((void **)&dI, sizeof(double) * 128 * 32));
     PMK_HIP(hipMalloc((void **)&dO, sizeof(double) * 128 * 32));
-    PMK_HIP(hipMemcpy(dL, Linv, sizeof(double) * 128 * 128, hipMemcpyHostToDevice));
+    PMK_HIP(hipMemcpy(dL, L, sizeof(double) * 128 * 128, hipMemcpyHostToDevice));
     PMK_HIP(hipMemcpy(dI, T_in, sizeof(double) * 128 * 32, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(selftest_trisolve_kernel, dim3(1), dim3(64), 0, ctx->stream, dL, dI, dO);
+    hipLaunchKernelGGL(selftest_trisolve_kernel, dim3(1), dim3(64), 0, ctx->stream, dL, dN, dI, dO);
     PMK_HIP(hipGetLastError());
     PMK_HIP(hipStreamSynchronize(ctx->stream));
     PMK_HIP(hipMemcpy(T_out, dO, sizeof(double) * 128 * 32, hipMemcpyDeviceToHost));
-    (void)hipFree(dL); (void)hipFree(dI); (void)hipFree(dO);
+    (void)hipFree(dL); (void)hipFree(dN); (void)hipFree(dI); (void)hipFree(dO);
     return 0;
 }
 

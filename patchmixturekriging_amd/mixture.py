@@ -88,7 +88,7 @@ class DeviceModel:
             ld = 0
         elif what == GET_LINV_DIAG:
             nt = (n + 127) // 128
-            out = np.empty((nt, 128, 128))
+            out = np.empty((4 * nt, 32, 32))
             ld = 0
         else:
             out = np.empty((n, n), order="F")

@@ -58,16 +58,21 @@ def test_mfma_fragment_layout_gemm():
 
 def test_mfma_trisolve_in_registers():
     import ctypes as C
+    import scipy.linalg as sla
     ctx = pmk.default_context()
     rng = np.random.default_rng(1)
-    Linv = np.tril(rng.integers(-4, 5, (128, 128))).astype(np.float64)
-    T = rng.integers(-4, 5, (128, 32)).astype(np.float64)
+    L = np.tril(rng.uniform(-1, 1, (128, 128))) + 8 * np.eye(128)      # asymmetric, well conditioned
+    ninv = np.stack([-np.linalg.inv(L[32 * s:32 * s + 32, 32 * s:32 * s + 32]) for s in range(4)])
+    T = rng.uniform(-4, 4, (128, 32))
     out = np.empty((128, 32))
     dp = C.POINTER(C.c_double)
-    Lf = np.asfortranarray(Linv)
-    rc = ctx.L.pmk_selftest_trisolve(ctx.h, Lf.ctypes.data_as(dp), T.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    Lf = np.asfortranarray(L)
+    Nf = np.ascontiguousarray(np.transpose(ninv, (0, 2, 1)))             # each block column-major
+    rc = ctx.L.pmk_selftest_trisolve(ctx.h, Lf.ctypes.data_as(dp), Nf.ctypes.data_as(dp), T.ctypes.data_as(dp),
+                                     out.ctypes.data_as(dp))
     assert rc == 0, ctx.L.pmk_last_error()
-    assert np.array_equal(out, Linv @ T)
+    ref = -sla.solve_triangular(L, T, lower=True)
+    assert np.abs(out - ref).max() <= 1e-13 * np.abs(ref).max()
 
 
 def test_mfma_peak_is_measured():
@@ -139,13 +144,16 @@ def _check_fit(model, r, X, y, th_o, sigma2, L_tol=1e-8):
     assert np.linalg.norm(c - f["c_chol"]) / np.linalg.norm(f["c_chol"]) <= 1e-6
     K = model.get(r, M.GET_K)                                   # U_set entry, rebuilt on demand
     assert np.array_equal(K, K.T) and ulps(K[f["K"] != 0], f["K"][f["K"] != 0]).max() <= 4
-    # inverted diagonal blocks really invert the diagonal blocks of L
-    Li = model.get(r, M.GET_LINV_DIAG)
-    for b in range(Li.shape[0]):
-        lo, hi = 128 * b, min(128 * (b + 1), n)
+    # the negated inverted 32 x 32 diagonal blocks (TRSM operands) really invert the blocks of L
+    Ni = model.get(r, M.GET_LINV_DIAG)
+    for b in range(Ni.shape[0]):
+        lo, hi = 32 * b, min(32 * (b + 1), n)
+        if lo >= n:
+            assert np.array_equal(Ni[b], -np.eye(32))            # identity padding
+            continue
         blk = L[lo:hi, lo:hi]
-        assert np.abs(Li[b][:hi - lo, :hi - lo] @ blk - np.eye(hi - lo)).max() < 1e-9
-        assert np.all(np.triu(Li[b], 1) == 0)
+        assert np.abs(-Ni[b][:hi - lo, :hi - lo] @ blk - np.eye(hi - lo)).max() < 1e-9
+        assert np.all(np.triu(Ni[b], 1) == 0)
     return c, L
 
 
