@@ -51,13 +51,6 @@ def panel_flops(ld, tile=128):
     return f
 
 
-class DevArray:
-    """a device buffer owned by the library, exposed to torch through __cuda_array_interface__"""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,26 +151,13 @@ def main():
     stage = {k: float(np.median(v)) for k, v in stage_ms.items() if v}
 
     # ---------------------------------------------------------------- predict
+    from patchmixturekriging_amd import dist as pdist
+
     def predict_step():
-        total = query.plan(radius, delta)                 # K5 + sort (blocks: sizes return to the host)
-        query.items(th)                                   # K4 on the owned regions
-        if world > 1:
-            u_ptr, v_ptr = query.item_buffers()
-            off = query.region_offsets(P * world)
-            seg = [int(off[(r + 1) * P] - off[r * P]) for r in range(world)]
-            mx = max(seg)
-            for ptr in (u_ptr, v_ptr):
-                full = torch.as_tensor(DevArray(ptr, total), device="cuda")
-                send = torch.zeros(mx, device="cuda", dtype=torch.float64)
-                send[:seg[rank]] = full[off[rank * P]:off[rank * P] + seg[rank]]
-                gathered = torch.empty(world * mx, device="cuda", dtype=torch.float64)
-                dist.all_gather_into_tensor(gathered, send)       # RCCL over xGMI: the path's one exchange
-                for r in range(world):
-                    if r != rank:
-                        full[off[r * P]:off[r * P] + seg[r]] = gathered[r * mx:r * mx + seg[r]]
-        q0, q1 = rank * args.nq, (rank + 1) * args.nq     # every rank blends its own slice of the queries
-        query.mix(wth, q0, q1)
-        return total
+        # plan (K5 + sort, replicated) -> items of the owned regions (K4) -> ONE all-gather of (u, v) over
+        # RCCL/xGMI -> mixture (K6) on this rank's slice of the queries
+        return pdist.sharded_predict(query, th, wth, radius, delta, P * world, rank, world,
+                                     nq_slice=(rank * args.nq, (rank + 1) * args.nq))
 
     ctx.L.pmk_ctx_enable_timers(ctx.h, 0)
     total_items = predict_step()

@@ -1,0 +1,431 @@
+# PatchMixtureKriging -- drop-in Julia front end of the MI355X implementation.
+#
+# Same module name, kernel types and fit/query API as RoyCCWang/PatchMixtureKriging, so that the
+# reference's examples/mixGP.jl and examples/IBB1D.jl run unchanged; every numerical method is a
+# `ccall` into libpmk_hip.so (C ABI: include/pmk.h).  Set ENV["PMK_LIB"] to the library path
+# (default: ../../../patchmixturekriging_amd/csrc/libpmk_hip.so relative to this file).
+#
+# NOTE: Julia is not installed in the build container, so this file has never been executed there.
+# It is kept mechanical and is mirrored 1:1 by the Python package patchmixturekriging_amd, which is
+# what the test-suite drives (see INTEGRATION.md).  Indices cross the ABI 0-based; this file adds 1.
+module PatchMixtureKriging
+
+using LinearAlgebra
+import Libdl
+
+const libpmk = get(ENV, "PMK_LIB",
+    normpath(joinpath(@__DIR__, "..", "..", "..", "patchmixturekriging_amd", "csrc", "libpmk_hip.so")))
+
+export RKHSProblemType, fitRKHS!, query!, constructkernelmatrix, evalkernel, evalquery,
+       setuppartition, getpartitionlines!, organizetrainingsets, fetchhyperplanes,
+       MixtureGPType, MixtureGPDebugType, fitmixtureGP!
+
+# ------------------------------------------------------------------------------------------ errors
+struct PMKError <: Exception
+    msg::String
+end
+lasterror() = unsafe_string(ccall((:pmk_last_error, libpmk), Cstring, ()))
+function check(rc::Integer, what::String)
+    rc < 0 && throw(PMKError("$what failed ($rc): $(lasterror())"))
+    return rc
+end
+
+# ------------------------------------------------------------------------------------------ context
+const CTX = Ref{Ptr{Cvoid}}(C_NULL)
+function context()
+    if CTX[] == C_NULL
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        dev = parse(Int, get(ENV, "PMK_DEVICE", "0"))
+        check(ccall((:pmk_ctx_create, libpmk), Cint, (Cint, Ref{Ptr{Cvoid}}), dev, h), "pmk_ctx_create")
+        CTX[] = h[]
+    end
+    return CTX[]
+end
+
+# ------------------------------------------------------------------------------------------ kernel types
+# same names and fields as src/misc/declarations.jl:18-111 of the reference
+abstract type StationaryKernelType end
+abstract type BrownianBridgeKernelType end
+struct Spline12KernelType{T} <: StationaryKernelType; a::T; end
+struct Spline32KernelType{T} <: StationaryKernelType; a::T; end
+struct Spline34KernelType{T} <: StationaryKernelType; a::T; end
+struct RationalQuadraticKernelType{T} <: StationaryKernelType; a::T; end
+struct TunableRationalQuadraticKernelType{T} <: StationaryKernelType; a::T; w::T; end
+struct ModulatedSqExpKernelType{T} <: StationaryKernelType; ϵ_sq::T; ν::T; end
+struct GaussianKernel1DType{T} <: StationaryKernelType; ϵ_sq::T; end
+struct BrownianBridge10{T} <: BrownianBridgeKernelType; a::T; end
+struct BrownianBridge20{T} <: BrownianBridgeKernelType; a::T; end
+struct BrownianBridge1ϵ{T} <: BrownianBridgeKernelType; ϵ::T; end
+struct BrownianBridge2ϵ{T} <: BrownianBridgeKernelType; ϵ::T; end
+struct BrownianBridgeSemiInfDomain{BT <: BrownianBridgeKernelType}; θ_base::BT; end
+
+# pmk_kernel_desc { int32 family; int32 flags; double p[4]; }
+struct KernelDesc
+    family::Int32
+    flags::Int32
+    p::NTuple{4,Float64}
+end
+desc(f, p1 = 0.0, p2 = 0.0; flags = 0) = KernelDesc(Int32(f), Int32(flags), (Float64(p1), Float64(p2), 0.0, 0.0))
+desc(θ::Spline34KernelType) = desc(1, θ.a[1])
+desc(θ::Spline12KernelType) = desc(2, θ.a[1])
+desc(θ::Spline32KernelType) = desc(3, θ.a[1])
+desc(θ::GaussianKernel1DType) = desc(4, θ.ϵ_sq[1])
+desc(θ::RationalQuadraticKernelType) = desc(5, θ.a[1])
+desc(θ::TunableRationalQuadraticKernelType) = desc(6, θ.a[1], θ.w[1])
+desc(θ::ModulatedSqExpKernelType) = desc(7, θ.ϵ_sq[1], θ.ν[1])
+desc(θ::BrownianBridge10) = desc(10, θ.a)
+desc(θ::BrownianBridge20) = desc(11, θ.a)
+desc(θ::BrownianBridge1ϵ) = desc(12, θ.ϵ)
+desc(θ::BrownianBridge2ϵ) = desc(13, θ.ϵ)
+function desc(θ::BrownianBridgeSemiInfDomain)
+    d = desc(θ.θ_base)
+    return KernelDesc(d.family, Int32(1), d.p)
+end
+
+# ------------------------------------------------------------------------------------------ helpers
+"""array2matrix (src/misc/utilities.jl:25-36): Vector{Vector{T}} -> D x N matrix"""
+function array2matrix(X::Vector{Vector{T}})::Matrix{T} where T
+    N = length(X); D = length(X[1])
+    out = Matrix{T}(undef, D, N)
+    for n = 1:N
+        out[:, n] = X[n]
+    end
+    return out
+end
+pack(X::Vector{Vector{T}}) where T = Matrix{Float64}(array2matrix(X))
+pack(X::Vector{T}) where T <: Real = reshape(Vector{Float64}(X), 1, length(X))
+
+"""convert2itpindex (src/misc/utilities.jl:562-579)"""
+function convert2itpindex(x::Vector{T}, a::Vector{T}, b::Vector{T}, M::Vector{Int})::Vector{T} where T <: Real
+    @assert length(x) == length(a) == length(b)
+    return collect((x[d] - a[d]) / (b[d] - a[d]) * (M[d] - 1) + 1 for d = 1:length(x))
+end
+
+# ------------------------------------------------------------------------------------------ kernel matrix
+"""constructkernelmatrix(X, θ)::Matrix{Float64} (src/RKHS/RKHS.jl:4-34); host matrix, exactly symmetric"""
+function constructkernelmatrix(X, θ)::Matrix{Float64}
+    Xm = pack(X); D, n = size(Xm)
+    K = Matrix{Float64}(undef, n, n)
+    d = Ref(desc(θ))
+    check(ccall((:pmk_kernel_matrix, libpmk), Cint,
+        (Ptr{Cvoid}, Ref{KernelDesc}, Cint, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64),
+        context(), d, D, n, Xm, n, C_NULL, K, n), "constructkernelmatrix")
+    return K
+end
+"""constructkernelmatrix(X, Z, θ) (src/RKHS/RKHS.jl:95-110)"""
+function constructkernelmatrix(X::Vector{Vector{T}}, Z::Vector{Vector{T}}, θ)::Matrix{T} where T
+    Xm = pack(X); Zm = pack(Z); D, n = size(Xm); m = size(Zm, 2)
+    K = Matrix{Float64}(undef, n, m)
+    d = Ref(desc(θ))
+    check(ccall((:pmk_kernel_matrix, libpmk), Cint,
+        (Ptr{Cvoid}, Ref{KernelDesc}, Cint, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64),
+        context(), d, D, n, Xm, m, Zm, K, n), "constructkernelmatrix")
+    return K
+end
+evalkernel(p::Vector{T}, q::Vector{T}, θ) where T = constructkernelmatrix([p], [q], θ)[1, 1]
+evalkernel(p::T, q::T, θ) where T <: Real = constructkernelmatrix([[p]], [[q]], θ)[1, 1]
+evalkernel(τ::T, θ::StationaryKernelType) where T <: Real = evalkernel([τ], [zero(T)], θ)
+
+# ------------------------------------------------------------------------------------------ BSP tree
+mutable struct HyperplaneType{T}          # partition.jl:3-9
+    v::Vector{T}
+    c::T
+    HyperplaneType{T}(v, c) where T = new{T}(v, c)
+    HyperplaneType{T}() where T = new{T}()
+end
+mutable struct PartitionDataType{T}       # partition.jl:11-16
+    hp::HyperplaneType{T}
+    X::Vector{Vector{T}}
+    global_X_indices::Vector{Int}
+    index::Int
+end
+mutable struct BinaryNode{T}              # partition.jl:18-29
+    data::T
+    parent::BinaryNode{T}
+    left::BinaryNode{T}
+    right::BinaryNode{T}
+    BinaryNode{T}(data) where T = new{T}(data)
+    BinaryNode{T}(data, parent::BinaryNode{T}) where T = new{T}(data, parent)
+end
+BinaryNode(data) = BinaryNode{typeof(data)}(data)
+
+# the native tree (pmk_bsp*) of every root returned by setuppartition
+const NATIVE = IdDict{Any,Ptr{Cvoid}}()
+native(root) = get(NATIVE, root) do
+    throw(PMKError("this node is not a root returned by setuppartition"))
+end
+
+function buildnodes(h::Ptr{Cvoid}, D::Int, levels::Int, X)
+    P = Int(ccall((:pmk_bsp_num_leaves, libpmk), Int64, (Ptr{Cvoid},), h))
+    N = Int(ccall((:pmk_bsp_num_points, libpmk), Int64, (Ptr{Cvoid},), h))
+    hv = Matrix{Float64}(undef, D, P - 1); hc = Vector{Float64}(undef, P - 1)
+    off = Vector{Int64}(undef, P + 1); inds = Vector{Int64}(undef, max(N, 1))
+    check(ccall((:pmk_bsp_arrays, libpmk), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}),
+        h, hv, hc, off, inds), "pmk_bsp_arrays")
+    T = Float64
+    k = Ref(0); leaf = Ref(0)
+    function make(parent, depth)
+        if depth == levels - 1
+            leaf[] += 1
+            gi = N > 0 ? Vector{Int}(inds[off[leaf[]]+1:off[leaf[]+1]] .+ 1) : Int[]
+            data = PartitionDataType(HyperplaneType{T}(), Vector{Vector{T}}(undef, 0), gi, leaf[])
+            return parent === nothing ? BinaryNode(data) : BinaryNode{typeof(data)}(data, parent)
+        end
+        k[] += 1
+        data = PartitionDataType(HyperplaneType{T}(hv[:, k[]], hc[k[]]), Vector{Vector{T}}(undef, 0), Int[], 0)
+        node = parent === nothing ? BinaryNode(data) : BinaryNode{typeof(data)}(data, parent)
+        node.left = make(node, depth + 1)       # pre-order: left subtree first
+        node.right = make(node, depth + 1)
+        return node
+    end
+    return make(nothing, 0), off, inds
+end
+
+"""setuppartition(X, level) -> root, X_parts, X_parts_inds (src/patchwork/partition.jl:106-129)"""
+function setuppartition(X::Vector{Vector{T}}, level; sign_mode::Int = 1) where T
+    Xm = pack(X); D, N = size(Xm)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pmk_bsp_build, libpmk), Cint, (Cint, Int64, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
+        D, N, Xm, level, sign_mode, h), "setuppartition")
+    root, off, inds = buildnodes(h[], D, Int(level), X)
+    NATIVE[root] = h[]
+    finalizer(r -> (ccall((:pmk_bsp_destroy, libpmk), Cvoid, (Ptr{Cvoid},), pop!(NATIVE, r, C_NULL)); nothing), root)
+    P = length(off) - 1
+    X_parts_inds = [Vector{Int}(inds[off[l]+1:off[l+1]] .+ 1) for l = 1:P]
+    X_parts = [Vector{Vector{Float64}}(X[ix]) for ix in X_parts_inds]      # labelleafnodes, partition.jl:131-159
+    return root, X_parts, X_parts_inds
+end
+
+"""findpartition(x, root, levels) (partition.jl:248-262), 1-based leaf index"""
+findpartition(x::Vector{T}, root, levels::Int) where T =
+    Int(ccall((:pmk_bsp_findpartition, libpmk), Int64, (Ptr{Cvoid}, Ptr{Float64}), native(root), Vector{Float64}(x))) + 1
+
+"""organizetrainingsets(root, levels, X0, ε) (partition.jl:301-357)"""
+function organizetrainingsets(root, levels::Int, X0::Vector{Vector{T}}, ε::T) where T
+    Xm = pack(X0); D, N = size(Xm)
+    h = native(root)
+    P = Int(ccall((:pmk_bsp_num_leaves, libpmk), Int64, (Ptr{Cvoid},), h))
+    off = Vector{Int64}(undef, P + 1)
+    sig = (Ptr{Cvoid}, Int64, Ptr{Float64}, Float64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64})
+    check(ccall((:pmk_bsp_assign, libpmk), Cint, sig, h, N, Xm, ε, off, C_NULL, C_NULL, C_NULL), "organizetrainingsets")
+    inds = Vector{Int64}(undef, max(off[end], 1)); loff = Vector{Int64}(undef, N + 1); lists = similar(inds)
+    check(ccall((:pmk_bsp_assign, libpmk), Cint, sig, h, N, Xm, ε, off, inds, loff, lists), "organizetrainingsets")
+    X_set_inds = [Vector{Int}(inds[off[r]+1:off[r+1]] .+ 1) for r = 1:P]
+    X_set = [X0[ix] for ix in X_set_inds]
+    regions_list_set = [Vector{Int}(lists[loff[n]+1:loff[n+1]] .+ 1) for n = 1:N]
+    problematic_inds = Vector{Vector{Int}}(undef, 0)
+    return X_set, X_set_inds, regions_list_set, problematic_inds
+end
+
+"""fetchhyperplanes(root): pre-order (src/RKHS/mixtureGP.jl:322-334)"""
+function fetchhyperplanes(root::BinaryNode{PartitionDataType{T}}) where T
+    hps = Vector{HyperplaneType{T}}(undef, 0)
+    function visit(node)
+        isdefined(node.data.hp, :v) && push!(hps, node.data.hp)
+        isdefined(node, :left) && visit(node.left)
+        isdefined(node, :right) && visit(node.right)
+    end
+    visit(root)
+    return hps
+end
+
+"""findneighbourpartitions(p, radius, root, levels, hps, home; δ) (mixtureGP.jl:339-405)"""
+function findneighbourpartitions(p::Vector{T}, radius::T, root, levels, hps, p_region_ind::Int; δ::T = 1e-10) where T
+    h = native(root); D = length(p); M = length(hps)
+    reg = Vector{Int64}(undef, max(M, 1)); ts = Vector{Float64}(undef, M); zs = Matrix{Float64}(undef, D, M)
+    keep = Vector{UInt8}(undef, M)
+    k = ccall((:pmk_bsp_neighbours, libpmk), Int64,
+        (Ptr{Cvoid}, Ptr{Float64}, Float64, Float64, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}),
+        h, Vector{Float64}(p), radius, δ, p_region_ind - 1, reg, ts, zs, keep)
+    check(k, "findneighbourpartitions")
+    return Vector{Int}(reg[1:k] .+ 1), ts, [zs[:, i] for i = 1:M], BitVector(keep .!= 0)
+end
+
+# plotting helpers of src/patchwork/visualize_2D.jl (host only)
+function get2Dline(u::Vector{T}, c::T) where T
+    return -u[1] / u[2], c / u[2]
+end
+function prunepartitionline(node, y::Vector{T}, t::Vector{T}) where T
+    @assert length(y) == length(t)
+    isdefined(node, :parent) || return y, t
+    c = node.parent.data.hp.c; v = node.parent.data.hp.v
+    isright = node.parent.right === node
+    keep = [xor(dot(v, [t[n]; y[n]]) < c, isright) for n = 1:length(t)]
+    return prunepartitionline(node.parent, y[keep], t[keep])
+end
+function getpartitionlines!(y_set::Vector{Vector{T}}, t_set, node::BinaryNode{PartitionDataType{T}}, level::Int,
+                            min_t, max_t, max_N_t::Int, centroid::Vector{T}, max_dist::T) where T
+    m, b = get2Dline(node.data.hp.v, node.data.hp.c)
+    t = collect(LinRange(min_t, max_t, max_N_t)); y = m .* t .+ b
+    near = [norm([t[n]; y[n]] - centroid) < max_dist for n = 1:length(t)]
+    y_pruned, t_pruned = prunepartitionline(node, y[near], t[near])
+    push!(y_set, y_pruned); push!(t_set, t_pruned)
+    if level != 2
+        getpartitionlines!(y_set, t_set, node.left, level - 1, min_t, max_t, max_N_t, centroid, max_dist)
+        getpartitionlines!(y_set, t_set, node.right, level - 1, min_t, max_t, max_N_t, centroid, max_dist)
+    end
+    return nothing
+end
+
+# ------------------------------------------------------------------------------------------ mixture GP
+mutable struct MixtureGPDebugType{T}      # mixtureGP.jl:5-35
+    w_tilde_set::Vector{Vector{T}}; u_set::Vector{Vector{T}}; v_set::Vector{Vector{T}}
+    region_inds_set::Vector{Vector{Int}}; p_region_ind_set::Vector{Int}
+    hps_keep_flags_set::Vector{BitVector}; zs_set::Vector{Vector{Vector{T}}}; ts_set::Vector{Vector{T}}
+end
+MixtureGPDebugType(dummy_val::T) where T = MixtureGPDebugType{T}([], [], [], [], [], [], [], [])
+
+mutable struct MixtureGPType{T}           # mixtureGP.jl:38-52 (+ the device model handle)
+    X_parts::Vector{Vector{Vector{T}}}
+    c_set::Vector{Vector{T}}
+    σ²_set::Vector{T}
+    U_set::Vector{Matrix{T}}
+    L_set::Vector{LowerTriangular{T,Matrix{T}}}
+    hps::Vector{HyperplaneType{T}}
+    model::Ptr{Cvoid}
+end
+function MixtureGPType(X_parts::Vector{Vector{Vector{T}}}, hps::Vector{HyperplaneType{T}}) where T
+    N = length(X_parts)
+    η = MixtureGPType(X_parts, Vector{Vector{T}}(undef, N), Vector{T}(undef, N), Vector{Matrix{T}}(undef, N),
+                      Vector{LowerTriangular{T,Matrix{T}}}(undef, N), hps, C_NULL)
+    finalizer(e -> (e.model != C_NULL && ccall((:pmk_model_destroy, libpmk), Cvoid, (Ptr{Cvoid},), e.model); nothing), η)
+    return η
+end
+
+function model_get(model::Ptr{Cvoid}, r::Int, what::Int, n::Int)
+    out = what == 0 ? Vector{Float64}(undef, n) : Matrix{Float64}(undef, n, n)
+    check(ccall((:pmk_model_get, libpmk), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Float64}, Int64), model, r - 1, what, out, n),
+          "pmk_model_get")
+    return out
+end
+
+"""fitmixtureGP!(η, y_parts, θ, σ²) -> η (mixtureGP.jl:70-118).  Pass store_factors=false to keep L_set/U_set
+on the device only (they are 2 x 8 n² bytes per patch on the host)."""
+function fitmixtureGP!(η::MixtureGPType{T}, y_parts::Vector{Vector{T}}, θ, σ²; store_factors::Bool = true) where T
+    P = length(η.X_parts)
+    Xm = [pack(X) for X in η.X_parts]; ys = [Vector{Float64}(y) for y in y_parts]
+    n = Int64[size(x, 2) for x in Xm]; D = size(Xm[1], 1)
+    for r = 1:P
+        @assert length(ys[r]) == n[r]                      # mixtureGP.jl:298
+    end
+    η.model != C_NULL && ccall((:pmk_model_destroy, libpmk), Cvoid, (Ptr{Cvoid},), η.model)
+    h = Ref{Ptr{Cvoid}}(C_NULL); info = Vector{Int32}(undef, P); d = Ref(desc(θ))
+    GC.@preserve Xm ys begin
+        rc = ccall((:pmk_fit_batched, libpmk), Cint,
+            (Ptr{Cvoid}, Ref{KernelDesc}, Float64, Cint, Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}},
+             Ref{Ptr{Cvoid}}, Ptr{Ptr{Float64}}, Ptr{Int32}),
+            context(), d, σ², D, P, n, [pointer(x) for x in Xm], [pointer(y) for y in ys], h, C_NULL, info)
+    end
+    check(rc, "fitmixtureGP!")
+    η.model = h[]
+    bad = findfirst(!=(0), info)
+    bad === nothing || throw(PosDefException(Int(info[bad])))       # cholesky(U) of mixtureGP.jl:109
+    for r = 1:P
+        η.c_set[r] = model_get(η.model, r, 0, Int(n[r]))
+        η.σ²_set[r] = σ²
+        if store_factors
+            η.L_set[r] = LowerTriangular(model_get(η.model, r, 1, Int(n[r])))
+            η.U_set[r] = model_get(η.model, r, 2, Int(n[r]))
+        end
+    end
+    return η
+end
+
+"""querymixtureGP!(Yq, Vq, Xq, η, root, levels, radius, δ, θ, σ², weight_θ, debug_vars; debug_flag)
+(mixtureGP.jl:159-294)"""
+function querymixtureGP!(Yq::Vector{T}, Vq::Vector{T}, Xq::Vector{Vector{T}}, η::MixtureGPType{T}, root, levels,
+                         radius::T, δ::T, θ, σ², weight_θ, debug_vars::MixtureGPDebugType{T};
+                         debug_flag = false)::Nothing where T
+    η.model == C_NULL && throw(PMKError("fitmixtureGP! must run before querymixtureGP!"))
+    Nq = length(Xq); Xm = pack(Xq)
+    resize!(Yq, Nq); resize!(Vq, Nq)                          # mixtureGP.jl:179-180
+    check(ccall((:pmk_model_set_bsp, libpmk), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), η.model, native(root), 0), "pmk_model_set_bsp")
+    q = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pmk_query_create, libpmk), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ref{Ptr{Cvoid}}), η.model, Nq, Xm, q), "pmk_query_create")
+    try
+        check(ccall((:pmk_query_plan, libpmk), Cint, (Ptr{Cvoid}, Float64, Float64), q[], radius, δ), "pmk_query_plan")
+        check(ccall((:pmk_query_items, libpmk), Cint, (Ptr{Cvoid}, Ref{KernelDesc}), q[], Ref(desc(θ))), "pmk_query_items")
+        check(ccall((:pmk_query_mix, libpmk), Cint, (Ptr{Cvoid}, Ref{KernelDesc}, Int64, Int64), q[], Ref(desc(weight_θ)), 0, Nq), "pmk_query_mix")
+        check(ccall((:pmk_query_fetch, libpmk), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), q[], Yq, Vq), "pmk_query_fetch")
+        if debug_flag
+            tot = Ref{Int64}(0)
+            check(ccall((:pmk_query_counts, libpmk), Cint, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}, Ptr{Int64}), q[], tot, C_NULL, C_NULL), "pmk_query_counts")
+            home = Vector{Int64}(undef, Nq); off = Vector{Int64}(undef, Nq + 1); reg = Vector{Int64}(undef, max(tot[], 1))
+            t = Vector{Float64}(undef, max(tot[], 1)); w = similar(t); u = similar(t); v = similar(t)
+            check(ccall((:pmk_query_debug, libpmk), Cint,
+                (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                q[], home, off, reg, t, w, u, v), "pmk_query_debug")
+            for j = 1:Nq
+                s = off[j]+1:off[j+1]
+                push!(debug_vars.w_tilde_set, w[s]); push!(debug_vars.u_set, u[s]); push!(debug_vars.v_set, v[s])
+                push!(debug_vars.region_inds_set, Vector{Int}(reg[s[1:end-1]] .+ 1))
+                push!(debug_vars.p_region_ind_set, Int(home[j]) + 1)
+                _, ts, zs, keep = findneighbourpartitions(Xq[j], radius, root, levels, η.hps, Int(home[j]) + 1; δ = δ)
+                push!(debug_vars.hps_keep_flags_set, keep); push!(debug_vars.zs_set, zs); push!(debug_vars.ts_set, ts)
+            end
+        end
+    finally
+        ccall((:pmk_query_destroy, libpmk), Cvoid, (Ptr{Cvoid},), q[])
+    end
+    return nothing
+end
+
+function querymixtureGP(Xq::Vector{Vector{T}}, η::MixtureGPType{T}, root, levels, radius::T, δ::T, θ, σ², weight_θ;
+                        debug_flag = false) where T
+    Yq = Vector{T}(undef, 0); Vq = Vector{T}(undef, 0)
+    debug_vars = MixtureGPDebugType(one(T))
+    querymixtureGP!(Yq, Vq, Xq, η, root, levels, radius, δ, θ, σ², weight_θ, debug_vars; debug_flag = debug_flag)
+    return Yq, Vq, debug_vars
+end
+querymixtureGP(xq::Vector{T}, η::MixtureGPType{T}, root, levels, radius::T, δ::T, θ, σ², weight_θ; debug_flag = false) where T <: Real =
+    querymixtureGP([xq], η, root, levels, radius, δ, θ, σ², weight_θ; debug_flag = debug_flag)
+
+# ------------------------------------------------------------------------------------------ single problem
+struct RKHSProblemType{Kernel_Type,T,X_Type}      # src/misc/declarations.jl:226-231
+    c::Vector{T}
+    X::Vector{X_Type}
+    θ::Kernel_Type
+    σ²::T
+end
+
+"""fitRKHS!(η, y): η.c[:] = (K + σ²I) \\ y (src/RKHS/RKHS.jl:182-217), one patch through the batched fit"""
+function fitRKHS!(η, y::Vector{T}) where T
+    @assert !isempty(η.X)
+    @assert !isempty(y)
+    @assert length(η.X) == length(y)
+    Xm = pack(η.X); yy = Vector{Float64}(y); D, n = size(Xm)
+    h = Ref{Ptr{Cvoid}}(C_NULL); info = Vector{Int32}(undef, 1); c = Vector{Float64}(undef, n); d = Ref(desc(η.θ))
+    GC.@preserve Xm yy c begin
+        rc = ccall((:pmk_fit_batched, libpmk), Cint,
+            (Ptr{Cvoid}, Ref{KernelDesc}, Float64, Cint, Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}},
+             Ref{Ptr{Cvoid}}, Ptr{Ptr{Float64}}, Ptr{Int32}),
+            context(), d, η.σ²[1], D, 1, Int64[n], [pointer(Xm)], [pointer(yy)], h, [pointer(c)], info)
+    end
+    check(rc, "fitRKHS!")
+    ccall((:pmk_model_destroy, libpmk), Cvoid, (Ptr{Cvoid},), h[])
+    info[1] == 0 || throw(PosDefException(Int(info[1])))
+    η.c[:] = c
+    return nothing
+end
+
+"""query!(Yq, Xq, η): mean only (src/RKHS/RKHS.jl:220-247)"""
+function query!(Yq::Vector{T}, Xq, η::RKHSProblemType) where T
+    @assert !isempty(Xq)
+    @assert size(Yq) == size(Xq)
+    Xm = pack(η.X); Qm = pack(Xq); D, n = size(Xm); Nq = size(Qm, 2)
+    out = Vector{Float64}(undef, Nq)
+    check(ccall((:pmk_query_mean, libpmk), Cint,
+        (Ptr{Cvoid}, Ref{KernelDesc}, Cint, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}),
+        context(), Ref(desc(η.θ)), D, n, Xm, Vector{Float64}(η.c), Nq, Qm, out), "query!")
+    Yq[:] = out
+    return nothing
+end
+
+"""evalquery(x, c, X, θ) (src/RKHS/querying.jl:2-5)"""
+function evalquery(x::Vector{T}, c::Vector{T}, X::Vector{Vector{T}}, θ)::T where T
+    y = Vector{T}(undef, 1)
+    query!(y, [x], RKHSProblemType(c, X, θ, zero(T)))
+    return y[1]
+end
+
+end # module

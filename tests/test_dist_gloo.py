@@ -1,0 +1,118 @@
+"""The N>1 path on CPU: world_size-2 (and 4) gloo process groups exercise the sharding arithmetic and the
+one exchange step of the predict path (patchmixturekriging_amd/dist.py) with the oracle standing in for the
+per-item GPU kernel, and check the blended result against the single-process oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from patchmixturekriging_amd import dist as pd          # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_ranges_and_segments():
+    assert [pd.leaf_range(r, 4, 16) for r in range(4)] == [(0, 4), (4, 8), (8, 12), (12, 16)]
+    assert pd.query_range(0, 2, 7) == (0, 3) and pd.query_range(1, 2, 7) == (3, 7)
+    off = np.array([0, 3, 3, 10, 12, 20, 20, 21, 30])
+    assert pd.segments(off, 2) == [(0, 12), (12, 18)]
+    assert pd.segments(off, 4) == [(0, 3), (3, 9), (12, 8), (20, 10)]
+    assert pd.segments(off, 1) == [(0, 30)]
+    with pytest.raises(ValueError):
+        pd.leaf_range(0, 3, 16)
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import patchmixturekriging_amd as pmk
+        from oracle import oracle as O
+        # a small mixGP problem, identical on every rank (seeded)
+        rng = np.random.Generator(np.random.PCG64(5))
+        N, levels, eps, a, sigma2, radius, delta = 600, 4, 0.5, 1 / 3.0, 1e-4, 0.6, 1e-5
+        X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+        y = np.sin(X[:, 0]) + 0.1 * X[:, 1]
+        Xq = np.stack([rng.uniform(-5, 5, 301), rng.uniform(-10, 10, 301)], 1)
+        root, _, _ = pmk.setuppartition(X, levels)                     # host BSP of the product (replicated)
+        X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, X, eps)
+        P = len(X_set)
+        oth, owth = O.kernel(O.SPLINE34, a), O.kernel(O.SPLINE34, 1 / radius)
+        lo, hi = pd.leaf_range(rank, world, P)
+        fits = {r: O.fit_patch(oth, X_set[r], y[X_set_inds[r]], sigma2) for r in range(lo, hi)}   # fit: no comm
+        # replicated plan = what pmk_query_plan produces: items in reference order, stably sorted by region
+        hps = pmk.fetchhyperplanes(root)
+        item_q, item_r, item_t, qoff = [], [], [], [0]
+        for j, x in enumerate(Xq):
+            home = pmk.findpartition(x, root)
+            reg, ts, _, keep = pmk.findneighbourpartitions(x, radius, root, levels, hps, home, delta=delta)
+            item_q += [j] * (len(reg) + 1); item_r += list(reg) + [home]; item_t += list(ts[keep]) + [0.0]
+            qoff.append(len(item_q))
+        item_r = np.array(item_r); item_q = np.array(item_q); item_t = np.array(item_t)
+        order = np.argsort(item_r, kind="stable")
+        roff = np.concatenate([[0], np.cumsum(np.bincount(item_r, minlength=P))])
+        pos = np.empty(len(order), dtype=np.int64); pos[order] = np.arange(len(order))
+        total = len(order)
+        u = torch.full((total,), float("nan"), dtype=torch.float64)
+        v = torch.full((total,), float("nan"), dtype=torch.float64)
+        s0, n0 = pd.segments(roff, world)[rank]
+        for k in range(s0, s0 + n0):                                   # items of the owned regions only
+            it = order[k]
+            f = fits[item_r[it]]
+            mu, var = O.queryinner(oth, X_set[item_r[it]], f["c_lu"], f["L"], Xq[item_q[it]])
+            u[k], v[k] = mu, var
+        pd.exchange_items(u, roff, rank, world)                        # the path's one collective
+        pd.exchange_items(v, roff, rank, world)
+        assert not torch.isnan(u).any() and not torch.isnan(v).any()
+        q0, q1 = pd.query_range(rank, world, len(Xq))
+        Yq, Vq = np.empty(q1 - q0), np.empty(q1 - q0)
+        for j in range(q0, q1):                                        # mixture on this rank's query slice
+            its = np.arange(qoff[j], qoff[j + 1])
+            w = np.array([O.profile(owth, abs(t)) for t in item_t[its[:-1]]] + [1.0])
+            w = w / w.sum()
+            Yq[j - q0] = w @ u[pos[its]].numpy()
+            Vq[j - q0] = w @ (v[pos[its]].numpy() * w)
+        np.savez(os.path.join(tmp, "rank%d.npz" % rank), Yq=Yq, Vq=Vq, q0=q0, q1=q1)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_predict_matches_single_process_oracle(world, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    import patchmixturekriging_amd as pmk
+    from oracle import oracle as O
+    rng = np.random.Generator(np.random.PCG64(5))
+    N, levels, eps, a, sigma2, radius, delta = 600, 4, 0.5, 1 / 3.0, 1e-4, 0.6, 1e-5
+    X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+    y = np.sin(X[:, 0]) + 0.1 * X[:, 1]
+    Xq = np.stack([rng.uniform(-5, 5, 301), rng.uniform(-10, 10, 301)], 1)
+    root, _, _ = pmk.setuppartition(X, levels)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, X, eps)
+    oth, owth = O.kernel(O.SPLINE34, a), O.kernel(O.SPLINE34, 1 / radius)
+    ob = O.BSP(X, levels)
+    fits = [O.fit_patch(oth, xs, y[i], sigma2) for xs, i in zip(X_set, X_set_inds)]
+    oY, oV = O.query_mixture(ob, oth, owth, X_set, [f["c_lu"] for f in fits], [f["L"] for f in fits], Xq, radius, delta)
+    got_Y, got_V = np.empty(len(Xq)), np.empty(len(Xq))
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        got_Y[int(d["q0"]):int(d["q1"])] = d["Yq"]
+        got_V[int(d["q0"]):int(d["q1"])] = d["Vq"]
+    assert np.allclose(got_Y, oY, rtol=0, atol=1e-12) and np.allclose(got_V, oV, rtol=1e-10, atol=1e-15)
