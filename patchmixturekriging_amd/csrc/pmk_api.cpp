@@ -112,6 +112,7 @@ int pmk_ctx_create(int device, pmk_ctx **out)
     PMK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     if (const char *e = getenv("PMK_FIT_GROUPS")) c->fit_groups = std::max(1, atoi(e));
+    if (const char *e = getenv("PMK_FUSE_K1")) c->fuse_k1 = atoi(e) != 0;
     *out = c;
     return 0;
 }
@@ -411,10 +412,10 @@ int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)
         // one stream, stage by stage (the per-stage timers bracket whole stages)
         c->tic("fit");
         c->tic("kernel_matrix");
-        if ((rc = launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P))) return rc;
+        if (!c->fuse_k1 && (rc = launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P))) return rc;
         c->toc("kernel_matrix");
         c->tic("cholesky");
-        if ((rc = launch_cholesky(m, c->stream, 0, m->P))) return rc;
+        if ((rc = launch_cholesky(m, c->stream, 0, m->P, c->fuse_k1))) return rc;
         c->toc("cholesky");
         c->tic("solve");
         if ((rc = launch_backsolve(m, c->stream, 0, m->P))) return rc;
@@ -436,8 +437,8 @@ int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)
             const int64_t p0 = m->P * g / G, p1 = m->P * (g + 1) / G;
             hipStream_t st = c->aux[(size_t)g];
             PMK_HIP(hipStreamWaitEvent(st, c->fork, 0));
-            if ((rc = launch_kernel_matrix_slabs(m, *th, sigma2, st, p0, p1 - p0))) return rc;
-            if ((rc = launch_cholesky(m, st, p0, p1 - p0))) return rc;
+            if (!c->fuse_k1 && (rc = launch_kernel_matrix_slabs(m, *th, sigma2, st, p0, p1 - p0))) return rc;
+            if ((rc = launch_cholesky(m, st, p0, p1 - p0, c->fuse_k1))) return rc;
             if ((rc = launch_backsolve(m, st, p0, p1 - p0))) return rc;
             PMK_HIP(hipEventRecord(c->aux_done[(size_t)g], st));
             PMK_HIP(hipStreamWaitEvent(c->stream, c->aux_done[(size_t)g], 0));
@@ -566,6 +567,7 @@ void pmk_query_destroy(pmk_query *q)
     dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_roff);
     dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w); dev_free(q->d_yq); dev_free(q->d_vq);
     if (q->d_tmp) (void)hipFree(q->d_tmp);
+    if (q->d_sort_scratch) (void)hipFree(q->d_sort_scratch);
     if (q->d_tasks) (void)hipFree(q->d_tasks);
     delete q;
 }
@@ -604,8 +606,6 @@ int pmk_query_plan(pmk_query *q, double radius, double delta)
     hipStream_t s = c->stream;
     c->tic("plan");
     q->planned = false;
-    dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
-    dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w);
     q->total = 0;
     q->roff.assign((size_t)(m->P_global + 1), 0);
     if (q->Nq > 0) {
@@ -619,16 +619,23 @@ int pmk_query_plan(pmk_query *q, double radius, double delta)
         PMK_HIP(hipMemcpyAsync(&q->total, q->d_qoff + q->Nq, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         PMK_HIP(hipStreamSynchronize(s));
         if (q->total > 0x7fffffff) { set_error("pmk_query_plan: too many work items (%lld)", (long long)q->total); return -5; }
-        rc = 0;
-        rc |= dev_alloc(&q->d_item_region, q->total);
-        rc |= dev_alloc(&q->d_item_t, q->total);
-        rc |= dev_alloc(&q->d_item_query, q->total);
-        rc |= dev_alloc(&q->d_sorted_item, q->total);
-        rc |= dev_alloc(&q->d_item_pos, q->total);
-        rc |= dev_alloc(&q->d_u, q->total);
-        rc |= dev_alloc(&q->d_v, q->total);
-        rc |= dev_alloc(&q->d_w, q->total);
-        if (rc) return -100;
+        if (q->total > q->item_cap) {          // grow only: repeated plans of one query batch reuse the buffers
+            dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
+            dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w);
+            q->item_cap = 0;
+            const int64_t cap = q->total + q->total / 8 + 1024;
+            rc = 0;
+            rc |= dev_alloc(&q->d_item_region, cap);
+            rc |= dev_alloc(&q->d_item_t, cap);
+            rc |= dev_alloc(&q->d_item_query, cap);
+            rc |= dev_alloc(&q->d_sorted_item, cap);
+            rc |= dev_alloc(&q->d_item_pos, cap);
+            rc |= dev_alloc(&q->d_u, cap);
+            rc |= dev_alloc(&q->d_v, cap);
+            rc |= dev_alloc(&q->d_w, cap);
+            if (rc) return -100;
+            q->item_cap = cap;
+        }
         if ((rc = launch_plan_fill(q, radius, delta, s))) return rc;
         if ((rc = launch_sort_items(q, s))) return rc;
         PMK_HIP(hipMemcpyAsync(q->roff.data(), q->d_roff, sizeof(int64_t) * q->roff.size(), hipMemcpyDeviceToHost, s));

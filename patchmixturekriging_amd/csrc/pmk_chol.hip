@@ -16,6 +16,8 @@
 //                       the serial diagonal kernel only ever sees one block column of GEMM.
 // The slab is read once per block column (left-looking): reads only, no trailing-matrix
 // read-modify-write.  chol_backsolve_kernel then gives c = L^-T z.
+#include <cstdlib>
+
 #include "pmk_mfma.h"
 
 namespace pmk {
@@ -36,13 +38,41 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
     return __hiloint2double(hi, lo);
 }
 
+// Fused kernel-matrix build (K1 folded into the factorisation): entry (i, j) of U = K + sigma2 I of a
+// patch, evaluated from the resident coordinates exactly as constructkernelmatrix! + the diagonal update
+// do (row point first for i >= j, mirrored above; src/RKHS/RKHS.jl:21-31, mixtureGP.jl:102-104), with the
+// identity padding of the slab.  FUSE = 0 reads the value kmat_slab_kernel wrote instead.
+template <int D, int FAM>
+struct TileSource {
+    const double *xs;     // SoA coordinates of the patch
+    int64_t ld;
+    int n;
+    double sigma2;
+    pmk_kernel_desc th;
+    __device__ __forceinline__ void point(int i, double *p) const
+    {
+#pragma unroll
+        for (int d = 0; d < D; ++d) p[d] = xs[(int64_t)d * ld + i];
+    }
+    __device__ __forceinline__ double value(int i, const double *pi, int j, const double *pj) const
+    {
+        double v = (i >= j) ? kern_eval<D, FAM>(th, pi, pj) : kern_eval<D, FAM>(th, pj, pi);
+        v = (i == j) ? v + sigma2 : v;
+        const bool inside = i < n && j < n;
+        return inside ? v : ((i == j) ? 1.0 : 0.0);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // diagonal block
 // ---------------------------------------------------------------------------------------------
+template <int D, int FAM, int FUSE>
 __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restrict__ descs, double *__restrict__ A,
                                                         double *__restrict__ ninv, const double *__restrict__ y,
                                                         const double *__restrict__ ytmp, double *__restrict__ z,
-                                                        int32_t *__restrict__ info, int k)
+                                                        int32_t *__restrict__ info, int k,
+                                                        const double *__restrict__ x, pmk_kernel_desc th, double sigma2,
+                                                        int skip)
 {
     const PatchDesc pd = descs[blockIdx.x];
     if (k >= pd.nt) return;
@@ -63,7 +93,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
     if (!(h == 0 && g == 1)) {
         WaveTile<2, 2> acc;
         acc.zero();
-        if (k > 0) {
+        if (k > 0 && !(skip & 16)) {
             const double *Lk = S + d0 + (d0 - TILE) * ld;      // L[k, k-1]: 128 x 128
             gemm_nt<2, 2, PF_DIAG>(acc, Lk + 64 * g, ld, Lk + 64 * h, ld, TILE, lane);
         }
@@ -75,7 +105,16 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
                 for (int pj = 0; pj < 2; ++pj) {
                     const int cl = 64 * g + 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * q) + (fi & 1);
                     const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
-                    const double2_t a = *reinterpret_cast<const double2_t *>(Akk + rl + (int64_t)cl * ld);
+                    double2_t a;
+                    if (FUSE && k == 0) {          // first tile: nothing was written to the slab, evaluate K here
+                        const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, sigma2, th};
+                        double pc[D], pr0[D], pr1[D];
+                        src.point(cl, pc); src.point(rl, pr0); src.point(rl + 1, pr1);
+                        a[0] = src.value(rl, pr0, cl, pc);
+                        a[1] = src.value(rl + 1, pr1, cl, pc);
+                    } else {
+                        a = *reinterpret_cast<const double2_t *>(Akk + rl + (int64_t)cl * ld);
+                    }
                     T[rl + cl * LDT] = a[0] - acc.f[fi][2 * pj][q];
                     T[rl + 1 + cl * LDT] = a[1] - acc.f[fi][2 * pj + 1][q];
                 }
@@ -97,84 +136,97 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
         rhs[tid] = base - (rhs[tid] + rhs[tid + TILE]);
     }
 
-    // ---- potrf of T in LDS, 32 columns at a time
-    for (int o = 0; o < TILE; o += SB) {
-        // (a) unblocked potrf of the 32 x 32 diagonal sub-block by the first 32 lanes of wave 0: lane i keeps
-        //     row i in registers, columns are broadcast with v_readlane (no LDS round trips in the chain)
-        if (wave == 0 && lane < SB) {
-            double row[SB];
+    // ---- potrf of T: right-looking, the tile distributed over the registers of all 256 threads
+    //      (thread (tr, tc) of a 16 x 16 grid holds A[tr + 16 a][tc + 16 b], a, b < 8).  Per pivot: the 16
+    //      threads that own column j scale it and publish it through LDS, one barrier, every thread applies
+    //      the rank-1 update to its own entries, one barrier.  The pivot's reciprocal square root comes from
+    //      v_rsq_f64 + two Newton steps (a dependent chain of ~10 FMAs instead of the IEEE sqrt + divide
+    //      sequences: the 128 pivots are a serial latency chain, this is its critical path).
+    __syncthreads();
+    {
+        __shared__ double col[TILE];
+        __shared__ double sdiag;
+        const int tr = tid & 15, tc = tid >> 4;
+        double a_[8][8];
 #pragma unroll
-            for (int l = 0; l < SB; ++l) row[l] = T[(o + lane) + (o + l) * LDT];
+        for (int a = 0; a < 8; ++a)
 #pragma unroll
-            for (int c = 0; c < SB; ++c) {
-                double d = readlane_f64(row[c], c);
+            for (int b2 = 0; b2 < 8; ++b2) a_[a][b2] = (b2 <= a) ? T[(tr + 16 * a) + (tc + 16 * b2) * LDT] : 0.0;
+        if (tid == 0) sdiag = T[0];
+        __syncthreads();
+        for (int j = 0; j < ((skip & 1) ? 0 : TILE); ++j) {
+            const int bj = j >> 4;
+            if (tc == (j & 15)) {
+                double d = sdiag;
                 if (!(d > 0.0)) {                         // not positive definite (or NaN): record, keep going
-                    if (lane == 0 && s_bad == 0) s_bad = k * TILE + o + c + 1;
+                    if (tr == 0 && s_bad == 0) s_bad = k * TILE + j + 1;
                     d = 1.0;
                 }
-                const double sq = sqrt(d);
-                row[c] = (lane == c) ? sq : row[c] / sq;
+                double rs = __builtin_amdgcn_rsq(d);
+                const double hd = 0.5 * d;
+                rs = __builtin_fma(rs, __builtin_fma(-hd * rs, rs, 0.5), rs);
+                rs = __builtin_fma(rs, __builtin_fma(-hd * rs, rs, 0.5), rs);
+                const double ljj = d * rs;
 #pragma unroll
-                for (int cc = c + 1; cc < SB; ++cc) row[cc] -= row[c] * readlane_f64(row[c], cc);
+                for (int b2 = 0; b2 < 8; ++b2)
+                    if (b2 == bj) {
+#pragma unroll
+                        for (int a = 0; a < 8; ++a) {
+                            const int r = tr + 16 * a;
+                            const double v = (r > j) ? a_[a][b2] * rs : ((r == j) ? ljj : a_[a][b2]);
+                            a_[a][b2] = v;
+                            col[r] = (r > j) ? v : 0.0;
+                        }
+                    }
             }
+            __syncthreads();
+            double cr[8], cc[8];
 #pragma unroll
-            for (int l = 0; l < SB; ++l)
-                if (l <= lane) T[(o + lane) + (o + l) * LDT] = row[l];
-        }
-        __syncthreads();
-        // (b) rows below: X = P D^-T, one thread per row, the row in registers;
-        //     wave 3 meanwhile inverts D (one thread per column of D^-1) and parks -D^-1
-        const int nbelow = TILE - o - SB;
-        if (tid < nbelow) {
-            const int r = o + SB + tid;
-            double p[SB];
+            for (int a = 0; a < 8; ++a) { cr[a] = col[tr + 16 * a]; cc[a] = col[tc + 16 * a]; }
 #pragma unroll
-            for (int l = 0; l < SB; ++l) p[l] = T[r + (o + l) * LDT];
+            for (int a = 0; a < 8; ++a)
+                if (16 * a + 15 > j) {
 #pragma unroll
-            for (int jj = 0; jj < SB; ++jj) {
-                double s = p[jj];
-#pragma unroll
-                for (int l = 0; l < jj; ++l) s -= p[l] * T[(o + jj) + (o + l) * LDT];
-                p[jj] = s / T[(o + jj) + (o + jj) * LDT];
-            }
-#pragma unroll
-            for (int l = 0; l < SB; ++l) T[r + (o + l) * LDT] = p[l];
-        } else if (tid >= 192 && tid < 192 + SB) {
-            const int c = tid - 192;
-            double x[SB];
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                double s = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int l = 0; l < i; ++l) s -= T[(o + i) + (o + l) * LDT] * x[l];
-                x[i] = s / T[(o + i) + (o + i) * LDT];
-            }
-#pragma unroll
-            for (int i = 0; i < SB; ++i) T[ninv_lds(o / SB, i, c)] = -x[i];
-        }
-        __syncthreads();
-        // (c) trailing update of the lower triangle: T[r][c] -= sum_l X[r][l] X[c][l]
-        if (nbelow > 0) {
-            const int tr = tid & 15, tc = tid >> 4;
-            const int b0 = o + SB;
-            for (int r = b0 + tr; r < TILE; r += 16) {
-                double pr[SB];
-#pragma unroll
-                for (int l = 0; l < SB; ++l) pr[l] = T[r + (o + l) * LDT];
-                for (int c = b0 + tc; c <= r; c += 16) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int l = 0; l < SB; ++l) s += pr[l] * T[c + (o + l) * LDT];
-                    T[r + c * LDT] -= s;
+                    for (int b2 = 0; b2 <= a; ++b2)
+                        if (16 * b2 + 15 > j) a_[a][b2] -= cr[a] * cc[b2];
                 }
+            // publish the next pivot's diagonal entry
+            if (j + 1 < TILE && tr == ((j + 1) & 15) && tc == ((j + 1) & 15)) {
+                const int bn = (j + 1) >> 4;
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+                    if (a == bn) sdiag = a_[a][a];
             }
+            __syncthreads();
         }
-        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 <= a; ++b2) {
+                const int r = tr + 16 * a, c = tc + 16 * b2;
+                if (r >= c) T[r + c * LDT] = a_[a][b2];
+            }
     }
+    __syncthreads();
+    // ---- negated inverses of the four 32 x 32 diagonal blocks: wave w inverts block w, one thread per column
+    if (lane < SB && !(skip & 2)) {
+        const int o = SB * wave, c = lane;
+        double x[SB];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int l = 0; l < i; ++l) sacc -= T[(o + i) + (o + l) * LDT] * x[l];
+            x[i] = sacc / T[(o + i) + (o + i) * LDT];
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) T[ninv_lds(wave, i, c)] = -x[i];
+    }
+    __syncthreads();
     if (tid == 0 && s_bad && info[blockIdx.x] == 0) info[blockIdx.x] = s_bad;
 
     // ---- L[kk] -> slab (lower; the strict upper part of the slab block is zeroed); -D^-1 blocks -> global
-    for (int e = tid; e < TILE * TILE; e += 256) {
+    for (int e = tid; e < ((skip & 4) ? 0 : TILE * TILE); e += 256) {
         const int i = e & 127, c = e >> 7;
         Akk[i + (int64_t)c * ld] = (i >= c) ? T[i + c * LDT] : 0.0;
     }
@@ -184,7 +236,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
         Ni[e] = (i >= c) ? T[ninv_lds(s, i, c)] : 0.0;
     }
     // ---- z_k = L[kk]^-1 rhs by block forward substitution (threads 0..31 own one 32-row block at a time)
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < ((skip & 8) ? 0 : 4); ++s) {
         if (tid < SB) {
             const int r = SB * s + tid;
             double v = rhs[r];
@@ -207,27 +259,34 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
 // block-row workgroup = one 128-row tile = 4 waves x (32 rows x 128 columns); the waves are
 // independent (no LDS, no barrier) and two workgroups share a CU (2 waves per SIMD)
 // ---------------------------------------------------------------------------------------------
+template <int D, int FAM, int FUSE>
 __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__restrict__ descs, double *__restrict__ A,
                                                             const double *__restrict__ ninv, const double *__restrict__ y,
-                                                            const double *__restrict__ z, double *__restrict__ ytmp, int k)
+                                                            const double *__restrict__ z, double *__restrict__ ytmp, int k,
+                                                            const double *__restrict__ x, pmk_kernel_desc th, double sigma2)
 {
-    const PatchDesc pd = descs[blockIdx.y];
+    // logical (block row, patch) from the XCD-aware id: all workgroups of a patch land on one XCD and
+    // share the I-operand (block row k of L) through that XCD's L2
+    const int lid = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int bx = lid % gridDim.x;
+    const PatchDesc pd = descs[lid / gridDim.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double *S = A + pd.aoff;
     const int64_t ld = pd.ld;
     const int64_t c0 = (int64_t)k * TILE;
 
-    if (blockIdx.x == gridDim.x - 1) {
+    if (bx == (int)gridDim.x - 1) {
         // ---- look-ahead for diagonal tile k+1: block columns 0..k-1 (column k is being produced by
         //      this very launch and is applied by the next diagonal kernel)
         const int64_t t0 = c0 + TILE;
         if (k + 1 >= pd.nt) return;
         const int h = wave >> 1, g = wave & 1;
-        if (k > 0 && !(h == 0 && g == 1)) {
+        if ((k > 0 || FUSE) && !(h == 0 && g == 1)) {
             WaveTile<2, 2> acc;
             acc.zero();
-            gemm_nt<2, 2, PF_DIAG>(acc, S + t0 + 64 * g, ld, S + t0 + 64 * h, ld, k * TILE, lane);
+            if (k > 0) gemm_nt<2, 2, PF_DIAG>(acc, S + t0 + 64 * g, ld, S + t0 + 64 * h, ld, k * TILE, lane);
             double *Att = S + t0 + t0 * ld;
+            const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, sigma2, th};
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
@@ -237,7 +296,16 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
                         const int cl = 64 * g + 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * q) + (fi & 1);
                         const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
                         double2_t *p = reinterpret_cast<double2_t *>(Att + rl + (int64_t)cl * ld);
-                        double2_t a = *p;
+                        double2_t a;
+                        if (FUSE) {
+                            double pc[D], pr0[D], pr1[D];
+                            const int gc = (int)t0 + cl, gr = (int)t0 + rl;
+                            src.point(gc, pc); src.point(gr, pr0); src.point(gr + 1, pr1);
+                            a[0] = src.value(gr, pr0, gc, pc);
+                            a[1] = src.value(gr + 1, pr1, gc, pc);
+                        } else {
+                            a = *p;
+                        }
                         a[0] -= acc.f[fi][2 * pj][q];
                         a[1] -= acc.f[fi][2 * pj + 1][q];
                         *p = a;
@@ -264,24 +332,41 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
 
     // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per
     // workgroup; the loads are in flight while the GEMM below runs
-    if ((int64_t)(k + 1 + blockIdx.x) * TILE >= pd.ld) return;      // whole workgroup: ld is a multiple of TILE
+    if ((int64_t)(k + 1 + bx) * TILE >= pd.ld) return;      // whole workgroup: ld is a multiple of TILE
     __shared__ double tri[TRI_LDS_DOUBLES];
     stage_tri_operands(tri, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
     __syncthreads();
-    const int64_t r0 = (int64_t)(k + 1 + blockIdx.x) * TILE + 32 * wave;
+    const int64_t r0 = (int64_t)(k + 1 + bx) * TILE + 32 * wave;
     double *out = S + r0 + 2 * (lane & 15) + (c0 + 2 * (lane >> 4)) * ld;   // element (fi = 0, q = 0)
 
     // acc starts as -A[rows, block column k]; the GEMM adds L[rows,0:k] L[k,0:k]^T, so acc = -T
     WaveTile<4, 1> acc;   // I = the 128 columns of block column k, J = 32 rows
+    if (FUSE) {
+        const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, sigma2, th};
+        const int gr = (int)r0 + 2 * (lane & 15);
+        double pr0[D], pr1[D];
+        src.point(gr, pr0); src.point(gr + 1, pr1);
 #pragma unroll
-    for (int fi = 0; fi < 8; ++fi)
+        for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cl = 32 * (fi >> 1) + 8 * q + (fi & 1);
-            const double2_t a = *reinterpret_cast<const double2_t *>(out + cl * ld);
-            acc.f[fi][0][q] = -a[0];
-            acc.f[fi][1][q] = -a[1];
-        }
+            for (int q = 0; q < 4; ++q) {
+                const int gc = (int)c0 + 2 * (lane >> 4) + 32 * (fi >> 1) + 8 * q + (fi & 1);
+                double pc[D];
+                src.point(gc, pc);
+                acc.f[fi][0][q] = -src.value(gr, pr0, gc, pc);
+                acc.f[fi][1][q] = -src.value(gr + 1, pr1, gc, pc);
+            }
+    } else {
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = 32 * (fi >> 1) + 8 * q + (fi & 1);
+                const double2_t a = *reinterpret_cast<const double2_t *>(out + cl * ld);
+                acc.f[fi][0][q] = -a[0];
+                acc.f[fi][1][q] = -a[1];
+            }
+    }
     if (k > 0) gemm_nt<4, 1, PF_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
     // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
     tri_solve_inplace<1>(acc, tri, lane);
@@ -354,7 +439,8 @@ __global__ __launch_bounds__(1024) void chol_backsolve_kernel(const PatchDesc *_
     for (int i = tid; i < pd.ld; i += 1024) cvec[pd.yoff + i] = cs[i];
 }
 
-int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
+template <int D, int FAM, int FUSE>
+static int launch_cholesky_T(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 {
     // gemm_nt consumes K in groups of 4*PF k-indices; K is always a multiple of TILE here
     static_assert(TILE % (4 * PF_DIAG) == 0 && TILE % (4 * PF_CHOL) == 0, "prefetch depth must divide TILE/4");
@@ -362,9 +448,10 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
     pmk_ctx *c = m->ctx;
     c->panel_n = 0;
     double *ytmp = m->d_c;      // the weight vector is free until the back substitution: scratch for y - L z
+    static const int dbg_skip = getenv("PMK_DBG_DIAG_SKIP") ? atoi(getenv("PMK_DBG_DIAG_SKIP")) : 0;   // timing experiments only
     for (int k = 0; k < m->max_nt; ++k) {
-        hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)np), dim3(256), 0, s, m->d_desc + p0, m->d_a, m->d_inv,
-                           m->d_y, ytmp, m->d_z, m->d_info + p0, k);
+        hipLaunchKernelGGL((chol_diag_kernel<D, FAM, FUSE>), dim3((unsigned)np), dim3(256), 0, s, m->d_desc + p0, m->d_a,
+                           m->d_inv, m->d_y, ytmp, m->d_z, m->d_info + p0, k, m->d_x, m->th, m->sigma2, dbg_skip);
         const int below = m->max_nt - k - 1;
         if (below > 0) {
             const bool fine = c->timers >= 2;
@@ -378,8 +465,8 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
                 PMK_HIP(hipEventRecord(c->panel_ev[(size_t)k].first, s));
             }
             // grid.x = block rows below + 1 look-ahead workgroup
-            hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(below + 1), (unsigned)np), dim3(256), 0, s,
-                               m->d_desc + p0, m->d_a, m->d_inv, m->d_y, m->d_z, ytmp, k);
+            hipLaunchKernelGGL((chol_panel_kernel<D, FAM, FUSE>), dim3((unsigned)(below + 1), (unsigned)np), dim3(256), 0, s,
+                               m->d_desc + p0, m->d_a, m->d_inv, m->d_y, m->d_z, ytmp, k, m->d_x, m->th, m->sigma2);
             if (fine) {
                 PMK_HIP(hipEventRecord(c->panel_ev[(size_t)k].second, s));
                 c->panel_n = k + 1;
@@ -388,6 +475,20 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
     }
     PMK_HIP(hipGetLastError());
     return 0;
+}
+
+// fuse != 0: the kernel matrix is evaluated inside the factorisation kernels (no kmat_slab_kernel pass)
+int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, int fuse)
+{
+    if (!fuse) return launch_cholesky_T<1, 0, 0>(m, s, p0, np);
+    const bool s34 = m->th.family == PMK_SPLINE34;
+    switch (m->D) {
+    case 1: return s34 ? launch_cholesky_T<1, PMK_SPLINE34, 1>(m, s, p0, np) : launch_cholesky_T<1, 0, 1>(m, s, p0, np);
+    case 2: return s34 ? launch_cholesky_T<2, PMK_SPLINE34, 1>(m, s, p0, np) : launch_cholesky_T<2, 0, 1>(m, s, p0, np);
+    case 3: return s34 ? launch_cholesky_T<3, PMK_SPLINE34, 1>(m, s, p0, np) : launch_cholesky_T<3, 0, 1>(m, s, p0, np);
+    case 4: return s34 ? launch_cholesky_T<4, PMK_SPLINE34, 1>(m, s, p0, np) : launch_cholesky_T<4, 0, 1>(m, s, p0, np);
+    default: set_error("unsupported input dimension %d", m->D); return -2;
+    }
 }
 
 int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)

@@ -67,6 +67,7 @@ struct pmk_ctx {
     int panel_n = 0;
     // the fit runs the patch batch as `fit_groups` independent sub-batches on side streams: the serial,
     // latency-bound diagonal-block kernel of one group overlaps the MFMA-bound panel kernel of the others
+    int fuse_k1 = 0;        // PMK_FUSE_K1=1 evaluates the kernel matrix inside the factorisation kernels; a tie on MI355X (profiles/r01_fuse_k1.txt), so the separately measurable K1 pass stays the default
     int fit_groups = 1;     // measured on MI355X (profiles/r01_fit_groups.txt): 1-2 groups tie, more are slower
     std::vector<hipStream_t> aux;
     std::vector<hipEvent_t> aux_done;
@@ -111,6 +112,7 @@ struct pmk_query {
     int32_t *d_cnt = nullptr;       // Nq : items per query (neighbours + 1)
     int64_t *d_qoff = nullptr;      // Nq+1
     int64_t total = 0;
+    int64_t item_cap = 0;           // capacity of the per-item buffers (reused across plans)
     int32_t *d_item_region = nullptr;   // total, reference order
     double *d_item_t = nullptr;         // total (0 for home)
     int32_t *d_item_query = nullptr;    // total
@@ -122,6 +124,7 @@ struct pmk_query {
     double *d_w = nullptr;                   // reference order (unnormalised), debug
     double *d_yq = nullptr, *d_vq = nullptr; // Nq
     void *d_tmp = nullptr; size_t tmp_bytes = 0;
+    void *d_sort_scratch = nullptr; int64_t sort_cap = 0;
     void *d_tasks = nullptr; int64_t ntasks = 0, strip_grid = 0;   // prediction strip tasks (owned regions)
     bool planned = false;
 };
@@ -134,7 +137,7 @@ int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, do
 int launch_kernel_matrix_dense(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
                                int64_t mcols, const double *d_zs, int64_t ldz, double *d_K, int64_t ldk,
                                bool symmetric, hipStream_t s);
-int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);
+int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, int fuse);
 int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);
 int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_plan_fill(pmk_query *q, double radius, double delta, hipStream_t s);

@@ -171,21 +171,38 @@ __device__ __forceinline__ int find_leaf(const double *__restrict__ hv, const do
     for (int l = 1; l < levels; ++l) {
         double u[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) u[d] = hv[(int64_t)node * D + d];
+        for (int d = 0; d < D; ++d) u[d] = hv[node * D + d];
         node = (dot_seq<D>(u, x) < hc[node]) ? 2 * node + 1 : 2 * node + 2;
     }
     return node - (int)(P - 1);
 }
 
-template <int D, bool FILL>
+// The tree (heap-order normals and offsets + the pre-order permutation) is staged in LDS once per
+// workgroup when it fits (P <= PLAN_LDS_NODES + 1): the hyperplane loop then reads LDS broadcasts instead
+// of issuing a dependent global load per hyperplane and per tree level.
+constexpr int PLAN_LDS_NODES = 2047;
+
+template <int D, bool FILL, bool LDS>
 __global__ __launch_bounds__(256) void plan_kernel(int64_t Nq, const double *__restrict__ xq,
-                                                   const double *__restrict__ hv, const double *__restrict__ hc,
-                                                   const int32_t *__restrict__ pre, int levels, int64_t P, double radius,
+                                                   const double *__restrict__ hv_g, const double *__restrict__ hc_g,
+                                                   const int32_t *__restrict__ pre_g, int levels, int64_t P, double radius,
                                                    double delta, int32_t *__restrict__ home_out,
                                                    int32_t *__restrict__ cnt_out, const int64_t *__restrict__ qoff,
                                                    int32_t *__restrict__ item_region, double *__restrict__ item_t,
                                                    int32_t *__restrict__ item_query)
 {
+    extern __shared__ double plan_sm[];
+    const double *hv = hv_g, *hc = hc_g;
+    const int32_t *pre = pre_g;
+    if (LDS) {
+        const int nn = (int)(P - 1);
+        double *sv = plan_sm, *sc = plan_sm + (size_t)nn * D;
+        int32_t *sp = reinterpret_cast<int32_t *>(sc + nn);
+        for (int e = threadIdx.x; e < nn * D; e += 256) sv[e] = hv_g[e];
+        for (int e = threadIdx.x; e < nn; e += 256) { sc[e] = hc_g[e]; sp[e] = pre_g[e]; }
+        __syncthreads();
+        hv = sv; hc = sc; pre = sp;
+    }
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= Nq) return;
     double p[D];
@@ -195,11 +212,11 @@ __global__ __launch_bounds__(256) void plan_kernel(int64_t Nq, const double *__r
     int count = 0;
     int64_t base = 0;
     if (FILL) base = qoff[j];
-    for (int64_t i = 0; i < P - 1; ++i) {
+    for (int i = 0; i < (int)(P - 1); ++i) {
         const int h = pre[i];
         double u[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) u[d] = hv[(int64_t)h * D + d];
+        for (int d = 0; d < D; ++d) u[d] = hv[h * D + d];
         const double c = hc[h];
         const double tt = -dot_seq<D>(u, p) + c;                 // mixtureGP.jl:361
         double r0 = (p[0] + tt * u[0]) - p[0];                   // z = p + t.*u ; norm(z - p)   :362,:367
@@ -237,21 +254,30 @@ __global__ __launch_bounds__(256) void plan_kernel(int64_t Nq, const double *__r
 }
 #pragma clang fp contract(fast)
 
-static int launch_plan(pmk_query *q, double radius, double delta, bool fill, hipStream_t s)
+template <int D>
+static int launch_plan_D(pmk_query *q, double radius, double delta, bool fill, hipStream_t s)
 {
     const pmk_model *m = q->m;
     dim3 grid((unsigned)((q->Nq + 255) / 256));
-    if (fill) {
-        PMK_DISPATCH_D(m->D, hipLaunchKernelGGL((plan_kernel<DD, true>), grid, dim3(256), 0, s, q->Nq, q->d_xq, m->d_hv,
-                                                m->d_hc, m->d_pre, m->levels, m->P_global, radius, delta, q->d_home,
-                                                q->d_cnt, q->d_qoff, q->d_item_region, q->d_item_t, q->d_item_query));
-    } else {
-        PMK_DISPATCH_D(m->D, hipLaunchKernelGGL((plan_kernel<DD, false>), grid, dim3(256), 0, s, q->Nq, q->d_xq, m->d_hv,
-                                                m->d_hc, m->d_pre, m->levels, m->P_global, radius, delta, q->d_home,
-                                                q->d_cnt, q->d_qoff, q->d_item_region, q->d_item_t, q->d_item_query));
-    }
+    const int64_t nn = m->P_global - 1;
+    const bool lds = nn <= PLAN_LDS_NODES;
+    const size_t bytes = lds ? (size_t)nn * (D + 1) * sizeof(double) + (size_t)nn * sizeof(int32_t) : 0;
+#define PMK_PLAN(FILL_, LDS_)                                                                                          \
+    hipLaunchKernelGGL((plan_kernel<D, FILL_, LDS_>), grid, dim3(256), bytes, s, q->Nq, q->d_xq, m->d_hv, m->d_hc,      \
+                       m->d_pre, m->levels, m->P_global, radius, delta, q->d_home, q->d_cnt, q->d_qoff,                \
+                       q->d_item_region, q->d_item_t, q->d_item_query)
+    if (fill) { if (lds) PMK_PLAN(true, true); else PMK_PLAN(true, false); }
+    else      { if (lds) PMK_PLAN(false, true); else PMK_PLAN(false, false); }
+#undef PMK_PLAN
     PMK_HIP(hipGetLastError());
     return 0;
+}
+
+static int launch_plan(pmk_query *q, double radius, double delta, bool fill, hipStream_t s)
+{
+    int rc = 0;
+    PMK_DISPATCH_D(q->m->D, rc = launch_plan_D<DD>(q, radius, delta, fill, s));
+    return rc;
 }
 
 int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s) { return launch_plan(q, radius, delta, false, s); }
@@ -305,9 +331,16 @@ int launch_sort_items(pmk_query *q, hipStream_t s)
     const int64_t n = q->total;
     const pmk_model *m = q->m;
     if (n == 0) return 0;
-    int32_t *keys_out = nullptr, *iota = nullptr;
-    PMK_HIP(hipMalloc((void **)&keys_out, sizeof(int32_t) * n));
-    PMK_HIP(hipMalloc((void **)&iota, sizeof(int32_t) * n));
+    // scratch for the sorted keys and the identity permutation, kept with the query (grow only)
+    if (q->sort_cap < n) {
+        if (q->d_sort_scratch) PMK_HIP(hipFree(q->d_sort_scratch));
+        q->d_sort_scratch = nullptr;
+        q->sort_cap = 0;
+        PMK_HIP(hipMalloc(&q->d_sort_scratch, sizeof(int32_t) * 2 * (size_t)(n + n / 8 + 1024)));
+        q->sort_cap = n + n / 8 + 1024;
+    }
+    int32_t *keys_out = reinterpret_cast<int32_t *>(q->d_sort_scratch);
+    int32_t *iota = keys_out + q->sort_cap;
     hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, iota, n);
     int bits = 1;
     while (((int64_t)1 << bits) < m->P_global) ++bits;
@@ -324,9 +357,6 @@ int launch_sort_items(pmk_query *q, hipStream_t s)
     hipLaunchKernelGGL(region_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys_out,
                        q->d_sorted_item, n, m->P_global, q->d_roff, q->d_item_pos);
     PMK_HIP(hipGetLastError());
-    PMK_HIP(hipStreamSynchronize(s));
-    PMK_HIP(hipFree(keys_out));
-    PMK_HIP(hipFree(iota));
     return 0;
 }
 

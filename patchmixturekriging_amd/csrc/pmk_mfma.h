@@ -11,6 +11,18 @@
 
 namespace pmk {
 
+// Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8) and every XCD has its own
+// L2.  xcd_remap() turns the hardware block id into a logical id such that each XCD works on one
+// contiguous range of logical ids, so workgroups that stream the same operand (the block rows of one
+// patch in the panel kernel, the strips of one region in prediction) share it through ONE L2 instead of
+// fetching it from HBM once per XCD.  Bijective for any grid size (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <int NPI, int NPJ>
 struct WaveTile {
     double4_t f[2 * NPI][2 * NPJ];

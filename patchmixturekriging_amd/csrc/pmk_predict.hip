@@ -38,7 +38,14 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
     double *V = strips + (int64_t)blockIdx.x * strip_stride + 32 * wave;   // this wave's 32 columns, ld = TQ
     __shared__ double tri[TRI_LDS_DOUBLES];     // TRSM operands of the current block row (shared by the 4 waves)
 
-    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    // XCD-aware task order: the workgroups of one XCD take consecutive tasks (= strips of the same
+    // region, which stream the same factor L) so that L is fetched into one L2 once per region
+    const int nround = (ntasks + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int round = 0; round < nround; ++round) {
+        const int base = round * (int)gridDim.x;
+        const int nin = min((int)gridDim.x, ntasks - base);          // tasks of this round
+        if ((int)blockIdx.x >= nin) break;
+        const int task = base + xcd_remap(blockIdx.x, nin);
         const StripTask tk = tasks[task];
         const bool active = 32 * wave < tk.count;     // wave-uniform; idle waves still help stage operands
         const PatchDesc pd = descs[tk.region];

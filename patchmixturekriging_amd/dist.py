@@ -50,7 +50,12 @@ def exchange_items(full, region_offsets, rank, world, group=None):
     send = torch.zeros(mx, dtype=full.dtype, device=full.device)
     send[:n0] = full[s0:s0 + n0]
     gathered = torch.empty(world * mx, dtype=full.dtype, device=full.device)
-    dist.all_gather_into_tensor(gathered, send, group=group)
+    try:
+        dist.all_gather_into_tensor(gathered, send, group=group)
+    except (RuntimeError, NotImplementedError):
+        # backends without allgather_base (gloo in the CPU tests / rehearsals): list form, same bytes
+        parts = [gathered[r * mx:(r + 1) * mx] for r in range(world)]
+        dist.all_gather(parts, send, group=group)
     for r, (s, n) in enumerate(seg):
         if r != rank and n:
             full[s:s + n] = gathered[r * mx:r * mx + n]
