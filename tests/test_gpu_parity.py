@@ -421,3 +421,70 @@ def test_config_C_full_size_properties():
         worst_y = max(worst_y, abs(Yq[j] - yj) / max(1, abs(yj)))
         worst_v = max(worst_v, abs(Vq[j] - vj) / (1e-9 + 1e-5 * vj))
     assert worst_y <= 1e-7 and worst_v <= 1.0, (worst_y, worst_v)
+
+
+# ------------------------------------------------------------------------------------ sharded predict (one process)
+def test_sharded_models_match_single_model():
+    """Two models that each own half of the leaves (what two ranks hold), the staged C-ABI calls with
+    leaf_base != 0, and the segment exchange of patchmixturekriging_amd.dist done by device copies: the blended
+    result must equal the single-model result bit for bit (same kernels, same order)."""
+    import torch
+    from patchmixturekriging_amd import dist as pd
+    X, y, Xq = _mixgp_case(4000, 4, 0.5, 1 / 4.0, 1e-5, 0.6, 1e-5, 1500, 11)
+    levels, radius, delta = 4, 0.6, 1e-5
+    th, wth = pmk.Spline34KernelType(1 / 4.0), pmk.Spline34KernelType(1 / radius)
+    root, _, _ = pmk.setuppartition(X, levels)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, X, 0.5)
+    P = len(X_set)
+    ys = [y[i] for i in X_set_inds]
+    full = pmk.DeviceModel(X_set, ys); full.fit(th, 1e-5); full.set_bsp(root, 0)
+    q = pmk.DeviceQuery(full, Xq); total = q.plan(radius, delta); q.items(th); q.mix(wth)
+    Y0, V0 = q.fetch()
+    world = 2
+    models, queries = [], []
+    for r in range(world):
+        lo, hi = pd.leaf_range(r, world, P)
+        m = pmk.DeviceModel(X_set[lo:hi], ys[lo:hi]); m.fit(th, 1e-5); m.set_bsp(root, lo)
+        qq = pmk.DeviceQuery(m, Xq)
+        assert qq.plan(radius, delta) == total            # replicated, deterministic plan
+        qq.items(th)
+        models.append(m); queries.append(qq)
+    off = queries[0].region_offsets(P)
+    assert np.array_equal(off, queries[1].region_offsets(P)) and np.array_equal(off, q.region_offsets(P))
+    seg = pd.segments(off, world)
+    assert (queries[0].first_owned, queries[0].num_owned) == seg[0] and (queries[1].first_owned, queries[1].num_owned) == seg[1]
+    pmk.default_context().synchronize()
+    bufs = [[torch.as_tensor(pd.DevArray(p, total), device="cuda") for p in qq.item_buffers()] for qq in queries]
+    for r in range(world):                                # what the all-gather does
+        for o in range(world):
+            if o != r:
+                s0, n0 = seg[o]
+                for a in range(2):
+                    bufs[r][a][s0:s0 + n0] = bufs[o][a][s0:s0 + n0]
+    torch.cuda.synchronize()
+    Y, V = np.empty(len(Xq)), np.empty(len(Xq))
+    for r in range(world):
+        q0, q1 = pd.query_range(r, world, len(Xq))
+        queries[r].mix(wth, q0, q1)
+        yr, vr = queries[r].fetch()
+        Y[q0:q1], V[q0:q1] = yr[q0:q1], vr[q0:q1]
+    assert np.array_equal(Y, Y0) and np.array_equal(V, V0)
+
+
+def test_empty_and_tiny_queries():
+    X, y, _ = _mixgp_case(500, 3, 0.3, 1 / 4.0, 1e-5, 0.5, 1e-5, 1, 4)
+    th, wth = pmk.Spline34KernelType(1 / 4.0), pmk.Spline34KernelType(2.0)
+    root, _, _ = pmk.setuppartition(X, 3)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, 3, X, 0.3)
+    m = pmk.DeviceModel(X_set, [y[i] for i in X_set_inds]); m.fit(th, 1e-5); m.set_bsp(root, 0)
+    q = pmk.DeviceQuery(m, np.empty((0, 2)))
+    assert q.plan(0.5, 1e-5) == 0
+    q.items(th); q.mix(wth)
+    Yq, Vq = q.fetch()
+    assert len(Yq) == 0 and len(Vq) == 0
+    # re-planning the same batch with another radius reuses the buffers and changes the item count
+    q2 = pmk.DeviceQuery(m, X[:300])
+    t_small = q2.plan(0.05, 1e-5); q2.items(th); q2.mix(wth); Ya, Va = q2.fetch()
+    t_big = q2.plan(2.0, 1e-5); q2.items(th); q2.mix(pmk.Spline34KernelType(0.5)); Yb, Vb = q2.fetch()
+    t_again = q2.plan(0.05, 1e-5); q2.items(th); q2.mix(wth); Yc, Vc = q2.fetch()
+    assert t_small <= t_big and t_again == t_small and np.array_equal(Ya, Yc) and np.array_equal(Va, Vc)
