@@ -243,7 +243,23 @@ def main():
         t_cpu_pred = time.perf_counter() - t
         err_y = float(np.max(np.abs(Yq[qs] - oY) / np.maximum(1, np.abs(oY)))) if len(qs) else 0.0
         err_v = float(np.max(np.abs(Vq[qs] - oV) / (1e-9 + 1e-5 * oV))) if len(qs) else 0.0
+        # "strong" flavour: same kernel loop, factorisations by LAPACK (scipy = OpenBLAS, the
+        # library family Julia's `\\` and `cholesky` reach), all host cores
+        strong = None
+        try:
+            import scipy.linalg as sla
+            t = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                Ks = list(ex.map(lambda r: O.kernel_matrix(oth, X_parts[r]), sample))
+            for r, K in zip(sample, Ks):
+                K[np.diag_indices_from(K)] += sigma2
+                sla.lu_solve(sla.lu_factor(K, check_finite=False), y[X_parts_inds[r]], check_finite=False)
+                sla.cholesky(K, lower=True, check_finite=False)
+            strong = len(sample) / (time.perf_counter() - t)
+        except Exception:
+            pass
         cpu = {"value": len(sample) / t_cpu_fit, "unit": "patch-solves/s", "cores": cores, "kind": "port",
+               "strong_lapack_patch_solves_per_s": strong,
                "sample": "%d of %d patches (n=%d) by the C oracle (kernel loop + LU + Cholesky), one patch per thread"
                          % (len(sample), P, n),
                "predict_points_per_s": len(qs) / t_cpu_pred if len(qs) else None,

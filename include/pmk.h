@@ -139,6 +139,16 @@ int  pmk_fit_batched(pmk_ctx *ctx, const pmk_kernel_desc *th, double sigma2, int
                      const int64_t *n, const double *const *X, const double *const *y,
                      pmk_model **out, double *const *c_out, int32_t *info);
 
+/* rebuild a device model from host factors (c_set, L_set of a fitted MixtureGPType; L[r] is n[r] x n[r]
+ * column-major with leading dimension ldl[r], lower triangle used): the checkpoint/resume path, and what
+ * queryinner(xq, X, theta, c, L) needs.  The TRSM operands are recomputed on the device. */
+int  pmk_model_load(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const double *const *X,
+                    const double *const *c, const double *const *L, const int64_t *ldl, pmk_model **out);
+/* queryinner(xq, X, theta, c, L)  src/RKHS/mixtureGP.jl:296-320, batched over Nq points against ONE patch:
+ * mu[j] = k(xq_j, X).c,  var[j] = clamp(k(xq_j,xq_j) - |L^-1 k(xq_j, X)|^2, 1e-12, inf).  No tree needed. */
+int  pmk_model_queryinner(pmk_model *m, int64_t patch, const pmk_kernel_desc *th, int64_t Nq, const double *Xq,
+                          double *mu, double *var);
+
 /* ---- predict -------------------------------------------------------------------------- */
 /* attach the tree; this model holds the global leaves [leaf_base, leaf_base + P) */
 int  pmk_model_set_bsp(pmk_model *m, const pmk_bsp *bsp, int64_t leaf_base);

@@ -380,6 +380,27 @@ end
 querymixtureGP(xq::Vector{T}, η::MixtureGPType{T}, root, levels, radius::T, δ::T, θ, σ², weight_θ; debug_flag = false) where T <: Real =
     querymixtureGP([xq], η, root, levels, radius, δ, θ, σ², weight_θ; debug_flag = debug_flag)
 
+"""queryinner(xq, X, θ, c, L) -> (μ, σ²) (mixtureGP.jl:296-320): host factors are uploaded with pmk_model_load and
+one strip of the prediction kernel runs against them"""
+function queryinner(xq::Vector{T}, X, θ, c, L) where T
+    Xm = pack(X); D, n = size(Xm)
+    cc = Vector{Float64}(c); Lm = Matrix{Float64}(L)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve Xm cc Lm begin
+        check(ccall((:pmk_model_load, libpmk), Cint,
+            (Ptr{Cvoid}, Cint, Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
+            context(), D, 1, Int64[n], [pointer(Xm)], [pointer(cc)], [pointer(Lm)], Int64[n], h), "pmk_model_load")
+    end
+    μ = Ref{Float64}(0.0); v = Ref{Float64}(0.0)
+    rc = ccall((:pmk_model_queryinner, libpmk), Cint,
+        (Ptr{Cvoid}, Int64, Ref{KernelDesc}, Int64, Ptr{Float64}, Ref{Float64}, Ref{Float64}),
+        h[], 0, Ref(desc(θ)), 1, Vector{Float64}(xq), μ, v)
+    ccall((:pmk_model_destroy, libpmk), Cvoid, (Ptr{Cvoid},), h[])
+    check(rc, "queryinner")
+    return μ[], v[]
+end
+queryinner!(kq::Vector{T}, xq, X, θ, c, L; min_v = 1e-12) where T = queryinner(xq, X, θ, c, L)
+
 # ------------------------------------------------------------------------------------------ single problem
 struct RKHSProblemType{Kernel_Type,T,X_Type}      # src/misc/declarations.jl:226-231
     c::Vector{T}

@@ -14,9 +14,10 @@ from .kernels import (BrownianBridge10, BrownianBridge1eps, BrownianBridge20,   
                       Spline12KernelType, Spline32KernelType, Spline34KernelType, StationaryKernelType,
                       TunableRationalQuadraticKernelType)
 from .mixture import (DeviceModel, DeviceQuery, MixtureGPDebugType, MixtureGPType,   # noqa: F401
-                      PosDefException, fit_patches, fitmixtureGP_, querymixtureGP, querymixtureGP_)
+                      PosDefException, fit_patches, fitmixtureGP_, queryinner, querymixtureGP, querymixtureGP_)
 from .partition import (BinaryNode, HyperplaneType, PartitionDataType, array2matrix,  # noqa: F401
                         convert2itpindex, fetchhyperplanes, findneighbourpartitions, findpartition,
+                        getpartitionlines_,
                         organizetrainingsets, setuppartition, tree_from_hyperplanes)
 from .rkhs import (RKHSProblemType, constructkernelmatrix, evalkernel, evalprofile,  # noqa: F401
                    evalquery, fitRKHS_, query_)

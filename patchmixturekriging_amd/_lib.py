@@ -75,6 +75,8 @@ SIGNATURES = {
     "pmk_model_num_patches": (C.c_int64, [_vp]),
     "pmk_model_destroy": (None, [_vp]),
     "pmk_fit_batched": (C.c_int, [_vp, _kp, C.c_double, C.c_int, C.c_int64, _ip, _dpp, _dpp, _vpp, _dpp, _i32p]),
+    "pmk_model_load": (C.c_int, [_vp, C.c_int, C.c_int64, _ip, _dpp, _dpp, _dpp, _ip, _vpp]),
+    "pmk_model_queryinner": (C.c_int, [_vp, C.c_int64, _kp, C.c_int64, _dp, _dp, _dp]),
     "pmk_model_set_bsp": (C.c_int, [_vp, _vp, C.c_int64]),
     "pmk_query_create": (C.c_int, [_vp, C.c_int64, _dp, _vpp]),
     "pmk_query_plan": (C.c_int, [_vp, C.c_double, C.c_double]),

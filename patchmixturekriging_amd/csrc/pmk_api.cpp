@@ -532,6 +532,76 @@ int pmk_fit_batched(pmk_ctx *ctx, const pmk_kernel_desc *th, double sigma2, int 
     return st;
 }
 
+int pmk_model_load(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const double *const *X, const double *const *c,
+                   const double *const *L, const int64_t *ldl, pmk_model **out)
+{
+    if (!out) { set_error("pmk_model_load: out is NULL"); return -9; }
+    *out = nullptr;
+    if (!c || !L || !ldl) { set_error("pmk_model_load: NULL factors"); return -6; }
+    // geometry + coordinates through the ordinary constructor (targets are not needed: pass c as a stand-in)
+    int rc = pmk_model_create(ctx, D, P, n, X, c, out);
+    if (rc) return rc;
+    pmk_model *m = *out;
+    std::vector<double> slab;
+    for (int64_t r = 0; r < P; ++r) {
+        const PatchDesc &d = m->desc[(size_t)r];
+        if (!L[r] || !c[r] || ldl[r] < d.n) { set_error("pmk_model_load: bad factor of patch %lld", (long long)r); pmk_model_destroy(m); *out = nullptr; return -7; }
+        slab.assign((size_t)d.ld * d.ld, 0.0);
+        for (int64_t j = 0; j < d.ld; ++j) {
+            if (j < d.n) for (int64_t i = j; i < d.n; ++i) slab[(size_t)(i + j * d.ld)] = L[r][i + j * ldl[r]];
+            else slab[(size_t)(j + j * d.ld)] = 1.0;                      // identity padding
+        }
+        PMK_HIP(hipMemcpy(m->d_a + d.aoff, slab.data(), sizeof(double) * slab.size(), hipMemcpyHostToDevice));
+        std::vector<double> cc((size_t)d.ld, 0.0);
+        std::memcpy(cc.data(), c[r], sizeof(double) * (size_t)d.n);
+        PMK_HIP(hipMemcpy(m->d_c + d.yoff, cc.data(), sizeof(double) * cc.size(), hipMemcpyHostToDevice));
+    }
+    if ((rc = launch_ninv_from_slabs(m, ctx->stream))) { pmk_model_destroy(m); *out = nullptr; return rc; }
+    PMK_HIP(hipStreamSynchronize(ctx->stream));
+    m->fitted = true;
+    return 0;
+}
+
+int pmk_model_queryinner(pmk_model *m, int64_t patch, const pmk_kernel_desc *th, int64_t Nq, const double *Xq,
+                         double *mu, double *var)
+{
+    if (!m || !m->fitted) { set_error("pmk_model_queryinner: model is not fitted"); return -1; }
+    if (patch < 0 || patch >= m->P) { set_error("pmk_model_queryinner: patch %lld of %lld", (long long)patch, (long long)m->P); return -2; }
+    if (!kernel_ok(th)) { set_error("pmk_model_queryinner: unknown kernel family"); return -3; }
+    if (Nq < 1 || Nq > 0x7fffffff || !Xq || !mu || !var) { set_error("pmk_model_queryinner: empty query"); return -4; }
+    pmk_ctx *c = m->ctx;
+    PMK_HIP(hipSetDevice(c->device));
+    // a plan by hand: every query is one item of region `patch`, already "sorted"
+    pmk_query q;
+    q.m = m; q.Nq = Nq; q.total = Nq;
+    int rc = 0;
+    rc |= dev_alloc(&q.d_xq, Nq * m->D);
+    rc |= dev_alloc(&q.d_sorted_item, Nq);
+    rc |= dev_alloc(&q.d_u, Nq);
+    rc |= dev_alloc(&q.d_v, Nq);
+    if (!rc) {
+        q.d_item_query = q.d_sorted_item;            // both are the identity permutation
+        q.roff.assign((size_t)(m->leaf_base + m->P + 1), 0);
+        for (int64_t r = m->leaf_base + patch + 1; r <= m->leaf_base + m->P; ++r) q.roff[(size_t)r] = Nq;
+        if (hipMemcpyAsync(q.d_xq, Xq, sizeof(double) * (size_t)(Nq * m->D), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -100;
+        if (!rc) rc = launch_iota(q.d_sorted_item, Nq, c->stream);
+        if (!rc) rc = build_strip_tasks(&q, c->stream);
+        if (!rc) rc = launch_items(&q, *th, c->stream);
+        if (!rc && (hipMemcpyAsync(mu, q.d_u, sizeof(double) * (size_t)Nq, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                    hipMemcpyAsync(var, q.d_v, sizeof(double) * (size_t)Nq, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                    hipStreamSynchronize(c->stream) != hipSuccess)) {
+            set_error("pmk_model_queryinner: copy back failed");
+            rc = -100;
+        }
+    } else {
+        rc = -100;
+    }
+    dev_free(q.d_xq); dev_free(q.d_sorted_item); dev_free(q.d_u); dev_free(q.d_v);
+    if (q.d_tasks) (void)hipFree(q.d_tasks);
+    q.d_item_query = nullptr;
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------ predict
 int pmk_model_set_bsp(pmk_model *m, const pmk_bsp *bsp, int64_t leaf_base)
 {

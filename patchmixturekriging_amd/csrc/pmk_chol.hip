@@ -491,6 +491,37 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, int fus
     }
 }
 
+// -(L[ss])^-1 of every 32 x 32 diagonal block of factors that were loaded from the host (pmk_model_load)
+__global__ __launch_bounds__(64) void ninv_from_slab_kernel(const PatchDesc *__restrict__ descs, const double *__restrict__ A,
+                                                            double *__restrict__ ninv)
+{
+    const PatchDesc pd = descs[blockIdx.y];
+    const int blk = blockIdx.x;                 // 32-block index along the diagonal
+    if (blk >= 4 * pd.nt) return;
+    const int c = threadIdx.x;
+    if (c >= SB) return;
+    const double *Dg = A + pd.aoff + (int64_t)SB * blk + (int64_t)SB * blk * pd.ld;
+    double x[SB];
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int l = 0; l < i; ++l) sacc -= Dg[i + (int64_t)l * pd.ld] * x[l];
+        x[i] = sacc / Dg[i + (int64_t)i * pd.ld];
+    }
+    double *out = ninv + pd.ioff + (int64_t)blk * (SB * SB);
+#pragma unroll
+    for (int i = 0; i < SB; ++i) out[i + SB * c] = (i >= c) ? -x[i] : 0.0;
+}
+
+int launch_ninv_from_slabs(pmk_model *m, hipStream_t s)
+{
+    hipLaunchKernelGGL(ninv_from_slab_kernel, dim3((unsigned)(4 * m->max_nt), (unsigned)m->P), dim3(64), 0, s, m->d_desc,
+                       m->d_a, m->d_inv);
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 {
     const size_t lds = sizeof(double) * ((size_t)m->max_nt * TILE + TILE);

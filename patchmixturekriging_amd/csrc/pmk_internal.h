@@ -139,6 +139,8 @@ int launch_kernel_matrix_dense(const pmk_kernel_desc &th, int D, int64_t n, cons
                                bool symmetric, hipStream_t s);
 int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, int fuse);
 int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);
+int launch_ninv_from_slabs(pmk_model *m, hipStream_t s);
+int launch_iota(int32_t *d, int64_t n, hipStream_t s);
 int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_plan_fill(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_sort_items(pmk_query *q, hipStream_t s);

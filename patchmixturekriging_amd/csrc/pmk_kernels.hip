@@ -310,6 +310,14 @@ __global__ void iota_kernel(int32_t *v, int64_t n)
     if (i < n) v[i] = (int32_t)i;
 }
 
+int launch_iota(int32_t *d, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, n);
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
 // region_offsets from the sorted keys + the inverse permutation
 __global__ void region_offsets_kernel(const int32_t *__restrict__ keys, const int32_t *__restrict__ sorted_item,
                                       int64_t n, int64_t P, int64_t *__restrict__ roff, int32_t *__restrict__ item_pos)

@@ -39,7 +39,7 @@ class PosDefException(np.linalg.LinAlgError):
 class DeviceModel:
     """pmk_model: the fitted per-patch factors, resident on the GPU"""
 
-    def __init__(self, X_parts, y_parts, ctx=None):
+    def __init__(self, X_parts, y_parts, ctx=None, _factors=None):
         self.ctx = ctx or default_context()
         L = self.ctx.L
         self.X = [as_points(x) for x in X_parts]
@@ -54,11 +54,32 @@ class DeviceModel:
                 raise ValueError("length(c) == length(X) must hold per patch")     # mixtureGP.jl:298
         PA = _dp * self.P
         h = C.c_void_p()
-        _lib.check(L.pmk_model_create(self.ctx.h, self.D, self.P, _i(self.n), PA(*[_d(x) for x in self.X]),
-                                      PA(*[_d(y) for y in ys]), C.byref(h)), "pmk_model_create")
+        if _factors is None:
+            _lib.check(L.pmk_model_create(self.ctx.h, self.D, self.P, _i(self.n), PA(*[_d(x) for x in self.X]),
+                                          PA(*[_d(y) for y in ys]), C.byref(h)), "pmk_model_create")
+        else:
+            Ls = [np.asfortranarray(l, dtype=np.float64) for l in _factors]
+            ldl = np.array([l.shape[0] for l in Ls], dtype=np.int64)
+            _lib.check(L.pmk_model_load(self.ctx.h, self.D, self.P, _i(self.n), PA(*[_d(x) for x in self.X]),
+                                        PA(*[_d(y) for y in ys]), PA(*[_d(l) for l in Ls]), _i(ldl), C.byref(h)),
+                       "pmk_model_load")
         self.h = h
         self.theta = None
         self.sigma2 = None
+
+    @classmethod
+    def from_factors(cls, X_parts, c_set, L_set, ctx=None):
+        """device model from host factors (c_set, L_set of a fitted MixtureGPType): checkpoint / resume"""
+        return cls(X_parts, c_set, ctx, _factors=L_set)
+
+    def queryinner(self, patch, theta, Xq):
+        """queryinner! batched over Xq against one patch -> (mu, var)"""
+        Xq = as_points(Xq)
+        mu, var = np.empty(Xq.shape[0]), np.empty(Xq.shape[0])
+        d = theta.desc()
+        _lib.check(self.ctx.L.pmk_model_queryinner(self.h, int(patch), C.byref(d), Xq.shape[0], _d(Xq), _d(mu), _d(var)),
+                   "pmk_model_queryinner")
+        return mu, var
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -274,3 +295,11 @@ def querymixtureGP(Xq, eta, root, levels, radius, delta, theta, sigma2, weight_t
     dbg = MixtureGPDebugType(1.0)
     querymixtureGP_(Yq, Vq, Xq, eta, root, levels, radius, delta, theta, sigma2, weight_theta, dbg, debug_flag)
     return Yq, Vq, dbg
+
+
+def queryinner(xq, X, theta, c, L):
+    """queryinner(xq, X, θ, c, L) -> (μ, σ²)   (mixtureGP.jl:296-320): the factors are uploaded
+    (pmk_model_load) and one strip of the prediction kernel runs against them"""
+    model = DeviceModel.from_factors([X], [c], [L])
+    mu, var = model.queryinner(0, theta, np.asarray(xq, dtype=np.float64)[None, :])
+    return float(mu[0]), float(var[0])

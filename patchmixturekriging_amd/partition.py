@@ -205,3 +205,37 @@ def convert2itpindex(x, a, b, M):
     M = np.asarray(M)
     assert len(x) == len(a) == len(b)
     return (x - a) / (b - a) * (M - 1) + 1
+
+
+# plotting helpers of src/patchwork/visualize_2D.jl (host only; called by examples/mixGP.jl:124)
+def get2Dline(u, c):
+    """dot(u, x) = c  ->  y = m t + b   (visualize_2D.jl:4-10)"""
+    return -u[0] / u[1], c / u[1]
+
+
+def prunepartitionline(node, y, t):
+    """keep the samples on this node's side of every ancestor's plane (visualize_2D.jl:53-83)"""
+    assert len(y) == len(t)
+    while node.parent is not None:
+        v, c = node.parent.data.hp.v, node.parent.data.hp.c
+        left = (v[0] * t + v[1] * y) < c
+        keep = ~left if node.parent.right is node else left
+        y, t = y[keep], t[keep]
+        node = node.parent
+    return y, t
+
+
+def getpartitionlines_(y_set, t_set, node, level, min_t, max_t, max_N_t, centroid, max_dist):
+    """getpartitionlines!(y_set, t_set, root, levels, min_t, max_t, max_N_t, centroid, max_dist)
+    (visualize_2D.jl:14-51): polyline samples of every split, pruned to its cell"""
+    m, b = get2Dline(node.data.hp.v, node.data.hp.c)
+    t = np.linspace(min_t, max_t, int(max_N_t))
+    y = m * t + b
+    near = np.hypot(t - centroid[0], y - centroid[1]) < max_dist
+    yp, tp = prunepartitionline(node, y[near], t[near])
+    y_set.append(yp)
+    t_set.append(tp)
+    if level != 2:
+        getpartitionlines_(y_set, t_set, node.left, level - 1, min_t, max_t, max_N_t, centroid, max_dist)
+        getpartitionlines_(y_set, t_set, node.right, level - 1, min_t, max_t, max_N_t, centroid, max_dist)
+    return None

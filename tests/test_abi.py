@@ -120,3 +120,19 @@ def test_tree_view_fields():
     assert [l.data.index for l in leaves] == [0, 1, 2, 3]      # dev/btree_easy.jl:56-68 left before right
     assert all(not l.data.hp.isdefined() and l.children() == () for l in leaves)
     assert np.array_equal(leaves[2].data.global_X_indices, inds[2])
+
+
+def test_getpartitionlines_host_helper():
+    # visualize_2D.jl:14-83: every returned sample lies on its split line and inside the cell of the node
+    rng = np.random.default_rng(2)
+    X = rng.uniform(-1, 1, (400, 2))
+    levels = 4
+    root, parts, _ = pmk.setuppartition(X, levels)
+    y_set, t_set = [], []
+    centroid = X.mean(0)
+    pmk.getpartitionlines_(y_set, t_set, root, levels, -2.0, 2.0, 500, centroid, 3.0)
+    hps = pmk.fetchhyperplanes(root)
+    assert len(y_set) == len(hps) == 2 ** (levels - 1) - 1          # pre-order, one polyline per split
+    for hp, y, t in zip(hps, y_set, t_set):
+        assert np.abs(hp.v[0] * t + hp.v[1] * y - hp.c).max() < 1e-12
+    assert len(t_set[0]) > len(t_set[1])                             # children are clipped by the parent plane

@@ -488,3 +488,26 @@ def test_empty_and_tiny_queries():
     t_big = q2.plan(2.0, 1e-5); q2.items(th); q2.mix(pmk.Spline34KernelType(0.5)); Yb, Vb = q2.fetch()
     t_again = q2.plan(0.05, 1e-5); q2.items(th); q2.mix(wth); Yc, Vc = q2.fetch()
     assert t_small <= t_big and t_again == t_small and np.array_equal(Ya, Yc) and np.array_equal(Va, Vc)
+
+
+def test_queryinner_and_model_load():
+    # queryinner(xq, X, theta, c, L) of the reference (mixtureGP.jl:296-320) with caller-supplied host factors
+    rng = np.random.default_rng(8)
+    X = rng.uniform(-3, 3, (333, 2))
+    y = np.cos(X[:, 0]) * X[:, 1]
+    th, oth = pmk.Spline34KernelType(0.3), O.kernel(O.SPLINE34, 0.3)
+    f = O.fit_patch(oth, X, y, 1e-5)
+    Xq = rng.uniform(-3, 3, (200, 2))
+    model = pmk.DeviceModel.from_factors([X], [f["c_lu"]], [f["L"]])
+    mu, var = model.queryinner(0, th, Xq)
+    for j in range(0, 200, 7):
+        omu, ovar = O.queryinner(oth, X, f["c_lu"], f["L"], Xq[j])
+        assert abs(mu[j] - omu) <= 1e-10 * max(1, abs(omu)) and abs(var[j] - ovar) <= 1e-9 + 1e-5 * ovar
+    m1, v1 = pmk.queryinner(Xq[3], X, th, f["c_lu"], f["L"])
+    assert m1 == mu[3] and v1 == var[3]
+    # a loaded model predicts like the model that was fitted on the device (checkpoint / resume)
+    fitted, cs, info = pmk.fit_patches([X], [y], th, 1e-5)
+    mu2, var2 = fitted.queryinner(0, th, Xq)
+    assert np.abs(mu2 - mu).max() < 1e-8 and np.all(np.abs(var2 - var) <= 1e-9 + 1e-5 * var)
+    Ni_loaded, Ni_fit = model.get(0, M.GET_LINV_DIAG), fitted.get(0, M.GET_LINV_DIAG)
+    assert np.abs(Ni_loaded - Ni_fit).max() < 1e-8
