@@ -108,7 +108,7 @@ def lib():
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is plumbing, not a requirement
         pass
-    path = build()
+    path = os.environ.get("PMK_LIB") or build()       # PMK_LIB: load an A/B variant build instead
     try:
         L = C.CDLL(path, mode=C.RTLD_GLOBAL)
     except OSError as e:

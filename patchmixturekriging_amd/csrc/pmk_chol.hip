@@ -23,7 +23,11 @@
 namespace pmk {
 
 constexpr int LDT = TILE + 1;   // LDS leading dimension of the diagonal tile (row access conflict-free)
-constexpr int PF_CHOL = 4;      // operand prefetch depth (k-steps) of the panel GEMM; must divide TILE/4
+constexpr int PF_CHOL = 4;      // I-operand prefetch depth (k-steps) of the panel GEMM; must divide TILE/4
+#ifndef PMK_PFJ
+#define PMK_PFJ 4
+#endif
+constexpr int PFJ_CHOL = PMK_PFJ;   // J-operand (own rows, HBM) prefetch depth
 constexpr int PF_DIAG = 4;
 constexpr int SB = 32;          // sub-block of the in-LDS potrf and of the TRSM block substitution
 
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
                 acc.f[fi][1][q] = -a[1];
             }
     }
-    if (k > 0) gemm_nt<4, 1, PF_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
+    if (k > 0) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
     // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
     tri_solve_inplace<1>(acc, tri, lane);
 #pragma unroll

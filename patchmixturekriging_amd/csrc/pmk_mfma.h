@@ -66,23 +66,48 @@ __device__ __forceinline__ void mfma_step(WaveTile<NPI, NPJ> &t, const OperandRe
 }
 
 // t[I][J] += sum_{k < K} MI[I, k] * MJ[J, k]   (opI = &MI[I0, 0], opJ = &MJ[J0, 0]; both column-major
-// with the tile index along the contiguous dimension).  K must be a positive multiple of 4*PF.
-template <int NPI, int NPJ, int PF>
+// with the tile index along the contiguous dimension).  The two operands are prefetched into separate
+// register rings: the I operand is shared by the workgroups of a patch / region and comes from L2
+// (depth PFI k-steps), the J operand is this wave's own stream from HBM and needs the deeper ring (PFJ,
+// a multiple of PFI).  K must be a positive multiple of 4*PFJ.
+template <int NPI, int NPJ, int PFI, int PFJ = PFI>
 __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const double *opI, int64_t ldI,
                                         const double *opJ, int64_t ldJ, int K, int lane)
 {
-    OperandRegs<NPI, NPJ> buf[PF];
+    static_assert(PFJ % PFI == 0, "the J ring depth must be a multiple of the I ring depth");
+    double2_t ra[PFI][NPI], rb[PFJ][NPJ];
 #pragma unroll
-    for (int s = 0; s < PF; ++s) load_operands(buf[s], opI, ldI, opJ, ldJ, 4 * s, lane);
-    for (int k0 = 0; k0 < K; k0 += 4 * PF) {
+    for (int s = 0; s < PFI; ++s)
 #pragma unroll
-        for (int s = 0; s < PF; ++s) {
-            mfma_step(t, buf[s]);
-            int kn = k0 + 4 * (s + PF);
-            kn = kn < K ? kn : K - 4;      // clamp: the tail re-reads the last step instead of branching
-            load_operands(buf[s], opI, ldI, opJ, ldJ, kn, lane);
-            // keep the refill of buffer s behind its own MFMAs: without this fence the scheduler hoists
-            // every load of the group to the loop head and doubles the operand registers (spills)
+        for (int pi = 0; pi < NPI; ++pi) ra[s][pi] = load_pair(opI + 32 * pi + (int64_t)(4 * s) * ldI, ldI, lane);
+#pragma unroll
+    for (int s = 0; s < PFJ; ++s)
+#pragma unroll
+        for (int pj = 0; pj < NPJ; ++pj) rb[s][pj] = load_pair(opJ + 32 * pj + (int64_t)(4 * s) * ldJ, ldJ, lane);
+    for (int k0 = 0; k0 < K; k0 += 4 * PFJ) {
+#pragma unroll
+        for (int s = 0; s < PFJ; ++s) {
+            const int si = s % PFI;
+#pragma unroll
+            for (int pi = 0; pi < NPI; ++pi)
+#pragma unroll
+                for (int ei = 0; ei < 2; ++ei)
+#pragma unroll
+                    for (int pj = 0; pj < NPJ; ++pj)
+#pragma unroll
+                        for (int ej = 0; ej < 2; ++ej)
+                            t.f[2 * pi + ei][2 * pj + ej] =
+                                mfma64(ra[si][pi][ei], rb[s][pj][ej], t.f[2 * pi + ei][2 * pj + ej]);
+            // refill both slots behind their own MFMAs; the tail re-reads the last k-step instead of branching
+            int ki = k0 + 4 * (s + PFI), kj = k0 + 4 * (s + PFJ);
+            ki = ki < K ? ki : K - 4;
+            kj = kj < K ? kj : K - 4;
+#pragma unroll
+            for (int pi = 0; pi < NPI; ++pi) ra[si][pi] = load_pair(opI + 32 * pi + (int64_t)ki * ldI, ldI, lane);
+#pragma unroll
+            for (int pj = 0; pj < NPJ; ++pj) rb[s][pj] = load_pair(opJ + 32 * pj + (int64_t)kj * ldJ, ldJ, lane);
+            // without this fence the scheduler hoists every load of the group to the loop head and doubles the
+            // operand registers (spills)
             __builtin_amdgcn_sched_barrier(0);
         }
     }

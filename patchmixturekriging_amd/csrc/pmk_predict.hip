@@ -11,11 +11,17 @@
 // Strip task, block row i:  acc(128 x 32) = Kq_i - sum_{j<i} L[i,j] V_j   (gemm_nt, V_j re-read from the
 // wave's strip in global memory, which is stored negated so the MFMA accumulates the subtraction)
 //                           -V_i = -L[ii]^-1 acc                          (tri_solve_inplace: block substitution)
+#include <cstdlib>
+
 #include "pmk_mfma.h"
 
 namespace pmk {
 
 constexpr int PF_PRED = 4;
+#ifndef PMK_PFJ
+#define PMK_PFJ 4
+#endif
+constexpr int PFJ_PRED = PMK_PFJ;   // J-operand (the wave's own strip columns, HBM) prefetch depth
 
 struct StripTask {
     int32_t region;    // local patch index in the model
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
             if (i > 0) {
                 // order this wave's earlier strip stores before its loads of them
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                gemm_nt<4, 1, PF_PRED>(acc, S + (int64_t)i * TILE, ld, V, TQ, i * TILE, lane);
+                gemm_nt<4, 1, PF_PRED, PFJ_PRED>(acc, S + (int64_t)i * TILE, ld, V, TQ, i * TILE, lane);
             }
             // ---- acc <- -V_i = -L[ii]^-1 acc   (block substitution; the strip wants -V anyway)
             tri_solve_inplace<1>(acc, tri, lane);

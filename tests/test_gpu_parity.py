@@ -511,3 +511,52 @@ def test_queryinner_and_model_load():
     assert np.abs(mu2 - mu).max() < 1e-8 and np.all(np.abs(var2 - var) <= 1e-9 + 1e-5 * var)
     Ni_loaded, Ni_fit = model.get(0, M.GET_LINV_DIAG), fitted.get(0, M.GET_LINV_DIAG)
     assert np.abs(Ni_loaded - Ni_fit).max() < 1e-8
+
+
+@pytest.mark.timeout(1200)
+def test_config_E_shape_in_fp64_properties():
+    """BASELINE config E shape (3-D stationary kernel, 128 BSP patches x 8192 points) run in fp64: the reference
+    is Float64-only (RKHS.jl:4-11), so the large-patch path (64 tile rows, 69 GB of slabs) is checked at full size
+    in the precision that has reference semantics; the fp32 variant is a later row.  One patch against LAPACK on
+    the oracle's kernel matrix, the batch through residual / interpolation properties."""
+    import scipy.linalg as sla
+    N, levels = 1 << 20, 8
+    rng = np.random.Generator(np.random.PCG64(7))
+    X = rng.uniform(0, 1, (N, 3))
+    y = np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) + X[:, 2] ** 2
+    a, sigma2 = 6.0, 1e-4                                   # support 1/a ~ 0.17 ~ patch width: compact, well conditioned
+    th, oth = pmk.Spline34KernelType(a), O.kernel(O.SPLINE34, a)
+    root, X_parts, X_parts_inds = pmk.setuppartition(X, levels)
+    assert [len(p) for p in X_parts] == [8192] * 128
+    model = pmk.DeviceModel(X_parts, [y[i] for i in X_parts_inds])
+    model.fit(th, sigma2)
+    assert np.all(model.info() == 0)
+    r = 77
+    Xr, yr = X_parts[r], y[X_parts_inds[r]]
+    U = O.kernel_matrix(oth, Xr) + sigma2 * np.eye(8192)
+    L, c = model.get(r, M.GET_L), model.get(r, M.GET_C)
+    Lref = sla.cholesky(U, lower=True, check_finite=False)
+    assert np.abs(L - Lref).max() < 1e-9
+    assert np.linalg.norm(U @ c - yr) / (np.linalg.norm(U) * np.linalg.norm(c) + np.linalg.norm(yr)) <= 1e-13
+    # predict: queries at training points of a few patches interpolate; variance within [1e-12, 1]
+    model.set_bsp(root, 0)
+    Xq = np.concatenate([X_parts[5][:3000], X_parts[120][:3000], rng.uniform(0, 1, (20000, 3))])
+    q = pmk.DeviceQuery(model, Xq)
+    total = q.plan(0.02, 1e-6); q.items(th); q.mix(pmk.Spline34KernelType(1 / 0.02))
+    Yq, Vq = q.fetch()
+    yt = np.concatenate([y[X_parts_inds[5][:3000]], y[X_parts_inds[120][:3000]]])
+    assert np.abs(Yq[:6000] - yt).max() < 5e-2 and np.median(np.abs(Yq[:6000] - yt)) < 1e-3
+    assert np.all(Vq >= 1e-12) and np.all(Vq <= 1 + 1e-9)
+    dbg = q.debug()
+    ob = O.BSP(X, levels)
+    for j in range(6000, 6400):
+        h = ob.findpartition(Xq[j])
+        reg, ts, _, keep = ob.neighbours(Xq[j], 0.02, 1e-6, h)
+        s = slice(dbg["item_offsets"][j], dbg["item_offsets"][j + 1])
+        assert dbg["home"][j] == h and np.array_equal(dbg["item_region"][s][:-1], reg)
+    # one (query, region) pair against the oracle's queryinner with the device factors
+    j = 6000 + int(np.argmax(dbg["home"][6000:] == r)) if np.any(dbg["home"][6000:] == r) else None
+    if j is not None:
+        s = slice(dbg["item_offsets"][j], dbg["item_offsets"][j + 1])
+        mu, var = O.queryinner(oth, Xr, c, L, Xq[j])
+        assert abs(dbg["item_u"][s][-1] - mu) <= 1e-9 * max(1, abs(mu)) and abs(dbg["item_v"][s][-1] - var) <= 1e-9 + 1e-5 * var
