@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix/vector peak (not in the local guide)
+FP32_PEAK_TFLOPS = 157.3    # fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
 def oracle_f(X):
@@ -60,6 +61,9 @@ def main():
     ap.add_argument("--patches", type=int, default=256, help="patches per GPU")
     ap.add_argument("--n", type=int, default=2000, help="points per patch")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--config", default="C", choices=["C", "E"],
+                    help="C: headline 2-D fp64 256 x 2000 (default).  E: 3-D, 128 x 8192, fp32 (BASELINE config E; "
+                         "not the headline: no CPU leg, fp32 MFMA peak)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,6 +96,9 @@ def main():
     ctx.set_stream(stream.cuda_stream)          # launch on torch's stream: its events then see our kernels
 
     # ---------------------------------------------------------------- synthetic input (config C, weak-scaled)
+    cfgE = args.config == "E"
+    if cfgE:
+        args.patches, args.n, args.no_cpu = 128, 8192, True
     P, n = args.patches, args.n
     levels_local = int(round(np.log2(P))) + 1
     assert 2 ** (levels_local - 1) == P, "--patches must be a power of two"
@@ -100,20 +107,27 @@ def main():
     N = P * n * world
     a, sigma2, delta = 1 / 15, 1e-5, 1e-5
     rng = np.random.Generator(np.random.PCG64(25))
-    X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
-    y = oracle_f(X)
+    if cfgE:
+        # unit cube, compact kernel (support ~0.6 patch widths) and a noise level that keep cond(U) * eps32 << 1
+        a, sigma2, delta = 8.0, 1e-3, 1e-6
+        X = rng.uniform(0, 1, (N, 3))
+        y = np.sin(3 * X[:, 0]) * np.cos(2 * X[:, 1]) + X[:, 2] ** 2
+    else:
+        X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+        y = oracle_f(X)
     t0 = time.time()
     root, X_parts, X_parts_inds = pmk.setuppartition(X, levels)        # host, exact; replicated on every rank
     t_bsp = time.time() - t0
     sizes = [len(p) for p in X_parts]
     # radius = 0.1 x patch width: patch area = 200 / (P world)
-    radius = 0.1 * np.sqrt(200.0 / (P * world))
+    radius = 0.1 * (1.0 / (P * world)) ** (1 / 3) if cfgE else 0.1 * np.sqrt(200.0 / (P * world))
     th, wth = pmk.Spline34KernelType(a), pmk.Spline34KernelType(1 / radius)
     lo, hi = rank * P, (rank + 1) * P
-    model = pmk.DeviceModel(X_parts[lo:hi], [y[i] for i in X_parts_inds[lo:hi]])
+    dtype = "f32" if cfgE else "f64"
+    model = pmk.DeviceModel(X_parts[lo:hi], [y[i] for i in X_parts_inds[lo:hi]], dtype=dtype)
     model.set_bsp(root, lo)
     Nq = args.nq * world
-    Xq = np.stack([rng.uniform(-5, 5, Nq), rng.uniform(-10, 10, Nq)], 1)
+    Xq = rng.uniform(0, 1, (Nq, 3)) if cfgE else np.stack([rng.uniform(-5, 5, Nq), rng.uniform(-10, 10, Nq)], 1)
     query = pmk.DeviceQuery(model, Xq)                                  # plan is replicated; items are sharded
 
     def sync():
@@ -196,7 +210,7 @@ def main():
     if "panel" in stage:
         flops = P * panel_flops(ld)
         roof = {"bound": "mfma", "kernel": "chol_panel_kernel", "achieved": flops / (stage["panel"] * 1e-3) / 1e12,
-                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                "peak": FP32_PEAK_TFLOPS if cfgE else FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
                 "launches_per_step": nt - 1, "avg_launch_ms": stage["panel"] / (nt - 1),
                 "alg_flops_per_launch": flops / (nt - 1)}
     elif "cholesky" in stage:
@@ -268,15 +282,18 @@ def main():
 
     ms = dt_fit / args.steps * 1e3
     out = {
-        "metric": "patch-solves/sec + predict-points/sec, 256 patches x 2k pts",
+        "metric": "patch-solves/sec + predict-points/sec, 256 patches x 2k pts" if not cfgE else
+                  "patch-solves/sec + predict-points/sec, 128 patches x 8k pts (config E)",
         "value": P * world * args.steps / dt_fit,
         "unit": "patch-solves/s",
         "predict_points_per_s": Nq * args.steps / dt_pred,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "predict_ms_per_step": dt_pred / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "mixGP 2-D Spline34(1/15), %d BSP patches x %d points per GPU, sigma2=1e-5 (BASELINE config C)"
+        "dtype": dtype, "data": "synthetic",
+        "config": {"workload": ("3-D Spline34(8), %d BSP patches x %d points per GPU, sigma2=1e-3, fp32 (BASELINE config E)"
+                                if cfgE else
+                                "mixGP 2-D Spline34(1/15), %d BSP patches x %d points per GPU, sigma2=1e-5 (BASELINE config C)")
                                % (P, n),
                    "patches_per_gpu": P, "points_per_patch": n, "patch_sizes_minmax": [min(sizes), max(sizes)],
                    "queries_per_gpu": args.nq, "radius": radius, "items_per_query": total_items / Nq,

@@ -56,6 +56,11 @@ typedef struct pmk_kernel_desc {
     double  p[4];
 } pmk_kernel_desc;
 
+/* arithmetic type of the device path.  The reference is Float64-only (RKHS.jl:4-11): PMK_F64 is the parity
+ * path; PMK_F32 (fp32 storage + v_mfma_f32, BASELINE config E) has no exact reference semantics and is judged
+ * against the fp64 oracle with eps32-scaled bounds.  Host buffers are double in both cases. */
+enum { PMK_F64 = 0, PMK_F32 = 1 };
+
 typedef struct pmk_ctx   pmk_ctx;    /* device + stream + workspaces */
 typedef struct pmk_bsp   pmk_bsp;    /* host BSP tree (root of setuppartition) */
 typedef struct pmk_model pmk_model;  /* fitted MixtureGPType on the device */
@@ -118,6 +123,9 @@ int pmk_kernel_matrix(pmk_ctx *ctx, const pmk_kernel_desc *th, int D,
  * n[r] points X[r] (D x n[r]) and targets y[r].  Inputs become device-resident. */
 int  pmk_model_create(pmk_ctx *ctx, int D, int64_t P, const int64_t *n,
                       const double *const *X, const double *const *y, pmk_model **out);
+/* same with an explicit arithmetic type (PMK_F64 / PMK_F32) */
+int  pmk_model_create_ex(pmk_ctx *ctx, int D, int64_t P, const int64_t *n,
+                         const double *const *X, const double *const *y, int dtype, pmk_model **out);
 /* fitmixtureGP!(eta, y_parts, theta, sigma2)  mixtureGP.jl:70-118 on the resident inputs:
  * per patch K (RKHS.jl:13-34), U = K + sigma2 I, L = chol(U), c = U^-1 y (one Cholesky
  * serves both; the reference's separate LU of :106 is not repeated).  Enqueues only. */

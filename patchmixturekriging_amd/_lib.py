@@ -68,6 +68,7 @@ SIGNATURES = {
     "pmk_bsp_neighbours": (C.c_int64, [_vp, _dp, C.c_double, C.c_double, C.c_int64, _ip, _dp, _dp, _bp]),
     "pmk_kernel_matrix": (C.c_int, [_vp, _kp, C.c_int, C.c_int64, _dp, C.c_int64, _dp, _dp, C.c_int64]),
     "pmk_model_create": (C.c_int, [_vp, C.c_int, C.c_int64, _ip, _dpp, _dpp, _vpp]),
+    "pmk_model_create_ex": (C.c_int, [_vp, C.c_int, C.c_int64, _ip, _dpp, _dpp, C.c_int, _vpp]),
     "pmk_model_fit": (C.c_int, [_vp, _kp, C.c_double]),
     "pmk_model_info": (C.c_int, [_vp, _i32p]),
     "pmk_model_set_targets": (C.c_int, [_vp, _dpp]),

@@ -56,6 +56,37 @@ static void dev_free(T *&p)
     p = nullptr;
 }
 
+// host double buffer -> device buffer of the model's element type (and back)
+static int upload_real(const pmk_model *m, void *dst, int64_t elem_off, const double *src, size_t count)
+{
+    if (m->dtype == PMK_F32) {
+        std::vector<float> tmp(count);
+        for (size_t i = 0; i < count; ++i) tmp[i] = (float)src[i];
+        PMK_HIP(hipMemcpy((char *)dst + elem_off * 4, tmp.data(), 4 * count, hipMemcpyHostToDevice));
+    } else {
+        PMK_HIP(hipMemcpy((char *)dst + elem_off * 8, src, 8 * count, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+// rows x cols block with device leading dimension ldd -> host leading dimension ldh (synchronous)
+static int download_real_2d(const pmk_model *m, double *dst, int64_t ldh, const void *src, int64_t elem_off, int64_t ldd,
+                            int64_t rows, int64_t cols, hipStream_t s)
+{
+    if (m->dtype == PMK_F32) {
+        std::vector<float> tmp((size_t)(rows * cols));
+        PMK_HIP(hipMemcpy2DAsync(tmp.data(), 4 * rows, (const char *)src + elem_off * 4, 4 * ldd, 4 * rows, (size_t)cols,
+                                 hipMemcpyDeviceToHost, s));
+        PMK_HIP(hipStreamSynchronize(s));
+        for (int64_t j = 0; j < cols; ++j)
+            for (int64_t i = 0; i < rows; ++i) dst[i + j * ldh] = (double)tmp[(size_t)(i + j * rows)];
+    } else {
+        PMK_HIP(hipMemcpy2DAsync(dst, 8 * ldh, (const char *)src + elem_off * 8, 8 * ldd, 8 * rows, (size_t)cols,
+                                 hipMemcpyDeviceToHost, s));
+        PMK_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
 // point-major host points (D x n) -> SoA rows of length ld.  Padding entries are 1e300: their distance
 // to any real point overflows to +inf, so a compactly supported profile evaluates to exactly 0 there.
 static void pack_soa(int D, int64_t n, int64_t ld, const double *X, double *out)
@@ -308,9 +339,11 @@ int pmk_query_mean(pmk_ctx *ctx, const pmk_kernel_desc *th, int D, int64_t n, co
 void pmk_model_destroy(pmk_model *m)
 {
     if (!m) return;
-    dev_free(m->d_desc); dev_free(m->d_x); dev_free(m->d_y); dev_free(m->d_z); dev_free(m->d_c);
-    dev_free(m->d_a); dev_free(m->d_inv); dev_free(m->d_info); dev_free(m->d_hv); dev_free(m->d_hc);
-    dev_free(m->d_pre); dev_free(m->d_strip);
+    dev_free(m->d_desc); dev_free(m->d_info); dev_free(m->d_hv); dev_free(m->d_hc); dev_free(m->d_pre);
+    for (void **p : {&m->d_x, &m->d_y, &m->d_z, &m->d_c, &m->d_a, &m->d_inv, &m->d_strip}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
     delete m;
 }
 
@@ -321,15 +354,21 @@ static int upload_targets(pmk_model *m, const double *const *y)
         if (!y[r]) { set_error("targets of patch %lld are NULL", (long long)r); return -6; }
         std::memcpy(hy.data() + m->desc[(size_t)r].yoff, y[r], sizeof(double) * (size_t)m->desc[(size_t)r].n);
     }
-    PMK_HIP(hipMemcpy(m->d_y, hy.data(), sizeof(double) * hy.size(), hipMemcpyHostToDevice));
-    return 0;
+    return upload_real(m, m->d_y, 0, hy.data(), hy.size());
 }
 
 int pmk_model_create(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const double *const *X,
                      const double *const *y, pmk_model **out)
 {
+    return pmk_model_create_ex(ctx, D, P, n, X, y, PMK_F64, out);
+}
+
+int pmk_model_create_ex(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const double *const *X,
+                        const double *const *y, int dtype, pmk_model **out)
+{
     if (!out) { set_error("pmk_model_create: out is NULL"); return -7; }
     *out = nullptr;
+    if (dtype != PMK_F64 && dtype != PMK_F32) { set_error("pmk_model_create: unknown dtype %d", dtype); return -8; }
     if (!ctx) { set_error("pmk_model_create: ctx is NULL"); return -1; }
     if (D < 1 || D > MAX_D) { set_error("pmk_model_create: D=%d outside 1..%d", D, MAX_D); return -2; }
     if (P < 1 || !n || !X || !y) { set_error("pmk_model_create: no patches"); return -3; }
@@ -337,6 +376,7 @@ int pmk_model_create(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const dou
     pmk_model *m = new (std::nothrow) pmk_model();
     if (!m) { set_error("out of memory"); return -100; }
     m->ctx = ctx; m->D = D; m->P = P;
+    m->dtype = dtype; m->esz = dtype == PMK_F32 ? 4 : 8;
     m->desc.resize((size_t)P);
     int64_t a = 0, xo = 0, yo = 0, io = 0;
     for (int64_t r = 0; r < P; ++r) {
@@ -361,12 +401,16 @@ int pmk_model_create(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const dou
     m->tot_a = a; m->tot_x = xo; m->tot_y = yo; m->tot_inv = io;
     int rc = 0;
     rc |= dev_alloc(&m->d_desc, P);
-    rc |= dev_alloc(&m->d_x, xo);
-    rc |= dev_alloc(&m->d_y, yo);
-    rc |= dev_alloc(&m->d_z, yo);
-    rc |= dev_alloc(&m->d_c, yo);
-    rc |= dev_alloc(&m->d_a, a);
-    rc |= dev_alloc(&m->d_inv, io);
+    auto alloc_real = [&](void **p, int64_t count) {
+        *p = nullptr;
+        return hipMalloc(p, m->esz * (size_t)std::max<int64_t>(count, 1)) == hipSuccess ? 0 : -100;
+    };
+    rc |= alloc_real(&m->d_x, xo);
+    rc |= alloc_real(&m->d_y, yo);
+    rc |= alloc_real(&m->d_z, yo);
+    rc |= alloc_real(&m->d_c, yo);
+    rc |= alloc_real(&m->d_a, a);
+    rc |= alloc_real(&m->d_inv, io);
     rc |= dev_alloc(&m->d_info, P);
     if (rc) { pmk_model_destroy(m); return -100; }
     {
@@ -375,7 +419,7 @@ int pmk_model_create(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const dou
             const PatchDesc &d = m->desc[(size_t)r];
             pack_soa(D, d.n, d.ld, X[r], hx.data() + d.xoff);
         }
-        if (hipMemcpy(m->d_x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        if (upload_real(m, m->d_x, 0, hx.data(), hx.size()) ||
             hipMemcpy(m->d_desc, m->desc.data(), sizeof(PatchDesc) * (size_t)P, hipMemcpyHostToDevice) != hipSuccess) {
             set_error("pmk_model_create: upload failed");
             pmk_model_destroy(m);
@@ -412,13 +456,13 @@ int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)
         // one stream, stage by stage (the per-stage timers bracket whole stages)
         c->tic("fit");
         c->tic("kernel_matrix");
-        if (!c->fuse_k1 && (rc = launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P))) return rc;
+        if (!c->fuse_k1 && (rc = PMK_BY_DTYPE(m, launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P)))) return rc;
         c->toc("kernel_matrix");
         c->tic("cholesky");
-        if ((rc = launch_cholesky(m, c->stream, 0, m->P, c->fuse_k1))) return rc;
+        if ((rc = PMK_BY_DTYPE(m, launch_cholesky(m, c->stream, 0, m->P, c->fuse_k1)))) return rc;
         c->toc("cholesky");
         c->tic("solve");
-        if ((rc = launch_backsolve(m, c->stream, 0, m->P))) return rc;
+        if ((rc = PMK_BY_DTYPE(m, launch_backsolve(m, c->stream, 0, m->P)))) return rc;
         c->toc("solve");
         c->toc("fit");
     } else {
@@ -437,9 +481,9 @@ int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)
             const int64_t p0 = m->P * g / G, p1 = m->P * (g + 1) / G;
             hipStream_t st = c->aux[(size_t)g];
             PMK_HIP(hipStreamWaitEvent(st, c->fork, 0));
-            if (!c->fuse_k1 && (rc = launch_kernel_matrix_slabs(m, *th, sigma2, st, p0, p1 - p0))) return rc;
-            if ((rc = launch_cholesky(m, st, p0, p1 - p0, c->fuse_k1))) return rc;
-            if ((rc = launch_backsolve(m, st, p0, p1 - p0))) return rc;
+            if (!c->fuse_k1 && (rc = PMK_BY_DTYPE(m, launch_kernel_matrix_slabs(m, *th, sigma2, st, p0, p1 - p0)))) return rc;
+            if ((rc = PMK_BY_DTYPE(m, launch_cholesky(m, st, p0, p1 - p0, c->fuse_k1)))) return rc;
+            if ((rc = PMK_BY_DTYPE(m, launch_backsolve(m, st, p0, p1 - p0)))) return rc;
             PMK_HIP(hipEventRecord(c->aux_done[(size_t)g], st));
             PMK_HIP(hipStreamWaitEvent(c->stream, c->aux_done[(size_t)g], 0));
         }
@@ -475,14 +519,10 @@ int pmk_model_get(pmk_model *m, int64_t patch, int what, double *out, int64_t ld
     if (what != PMK_GET_K && !m->fitted) { set_error("pmk_model_get: model is not fitted"); return -3; }
     switch (what) {
     case PMK_GET_C:
-        PMK_HIP(hipMemcpyAsync(out, m->d_c + d.yoff, sizeof(double) * (size_t)d.n, hipMemcpyDeviceToHost, c->stream));
-        PMK_HIP(hipStreamSynchronize(c->stream));
-        return 0;
+        return download_real_2d(m, out, d.n, m->d_c, d.yoff, d.ld, d.n, 1, c->stream);
     case PMK_GET_L: {
         if (ld < d.n) { set_error("pmk_model_get: ld too small"); return -5; }
-        PMK_HIP(hipMemcpy2DAsync(out, sizeof(double) * ld, m->d_a + d.aoff, sizeof(double) * d.ld, sizeof(double) * d.n,
-                                 (size_t)d.n, hipMemcpyDeviceToHost, c->stream));
-        PMK_HIP(hipStreamSynchronize(c->stream));
+        if (int rc = download_real_2d(m, out, ld, m->d_a, d.aoff, d.ld, d.n, d.n, c->stream)) return rc;
         for (int64_t j = 1; j < d.n; ++j)
             for (int64_t i = 0; i < j; ++i) out[i + j * ld] = 0.0;   // .L of the reference: strict upper = 0
         return 0;
@@ -491,23 +531,25 @@ int pmk_model_get(pmk_model *m, int64_t patch, int what, double *out, int64_t ld
         // U_set entry (mixtureGP.jl:99): K without noise, rebuilt on demand from the resident points
         if (ld < d.n) { set_error("pmk_model_get: ld too small"); return -5; }
         if (!kernel_ok(&m->th)) { set_error("pmk_model_get: no kernel set (fit first)"); return -3; }
-        double *dK = nullptr;
-        if (dev_alloc(&dK, (int64_t)d.n * d.n)) return -100;
-        int rc = launch_kernel_matrix_dense(m->th, m->D, d.n, m->d_x + d.xoff, d.ld, d.n, m->d_x + d.xoff, d.ld, dK, d.n,
-                                            true, c->stream);
+        double *dK = nullptr, *dxs = nullptr;
+        if (dev_alloc(&dK, (int64_t)d.n * d.n) || dev_alloc(&dxs, (int64_t)d.ld * m->D)) return -100;
+        {   // the dense host-API kernel is fp64: give it fp64 coordinates whatever the model's element type
+            std::vector<double> hx((size_t)(d.ld * m->D));
+            if (int rc2 = download_real_2d(m, hx.data(), d.ld, m->d_x, d.xoff, d.ld, d.ld, m->D, c->stream)) return rc2;
+            PMK_HIP(hipMemcpy(dxs, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+        }
+        int rc = launch_kernel_matrix_dense(m->th, m->D, d.n, dxs, d.ld, d.n, dxs, d.ld, dK, d.n, true, c->stream);
         if (!rc) {
             PMK_HIP(hipMemcpy2DAsync(out, sizeof(double) * ld, dK, sizeof(double) * d.n, sizeof(double) * d.n, (size_t)d.n,
                                      hipMemcpyDeviceToHost, c->stream));
             PMK_HIP(hipStreamSynchronize(c->stream));
         }
-        dev_free(dK);
+        dev_free(dK); dev_free(dxs);
         return rc;
     }
     case PMK_GET_LINV_DIAG:
-        PMK_HIP(hipMemcpyAsync(out, m->d_inv + d.ioff, sizeof(double) * (size_t)d.nt * 4 * 32 * 32, hipMemcpyDeviceToHost,
-                               c->stream));
-        PMK_HIP(hipStreamSynchronize(c->stream));
-        return 0;
+        return download_real_2d(m, out, (int64_t)d.nt * 4096, m->d_inv, d.ioff, (int64_t)d.nt * 4096, (int64_t)d.nt * 4096, 1,
+                                c->stream);
     default:
         set_error("pmk_model_get: unknown selector %d", what);
         return -3;
@@ -551,12 +593,12 @@ int pmk_model_load(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const doubl
             if (j < d.n) for (int64_t i = j; i < d.n; ++i) slab[(size_t)(i + j * d.ld)] = L[r][i + j * ldl[r]];
             else slab[(size_t)(j + j * d.ld)] = 1.0;                      // identity padding
         }
-        PMK_HIP(hipMemcpy(m->d_a + d.aoff, slab.data(), sizeof(double) * slab.size(), hipMemcpyHostToDevice));
+        if ((rc = upload_real(m, m->d_a, d.aoff, slab.data(), slab.size()))) return rc;
         std::vector<double> cc((size_t)d.ld, 0.0);
         std::memcpy(cc.data(), c[r], sizeof(double) * (size_t)d.n);
-        PMK_HIP(hipMemcpy(m->d_c + d.yoff, cc.data(), sizeof(double) * cc.size(), hipMemcpyHostToDevice));
+        if ((rc = upload_real(m, m->d_c, d.yoff, cc.data(), cc.size()))) return rc;
     }
-    if ((rc = launch_ninv_from_slabs(m, ctx->stream))) { pmk_model_destroy(m); *out = nullptr; return rc; }
+    if ((rc = PMK_BY_DTYPE(m, launch_ninv_from_slabs(m, ctx->stream)))) { pmk_model_destroy(m); *out = nullptr; return rc; }
     PMK_HIP(hipStreamSynchronize(ctx->stream));
     m->fitted = true;
     return 0;
@@ -585,8 +627,8 @@ int pmk_model_queryinner(pmk_model *m, int64_t patch, const pmk_kernel_desc *th,
         for (int64_t r = m->leaf_base + patch + 1; r <= m->leaf_base + m->P; ++r) q.roff[(size_t)r] = Nq;
         if (hipMemcpyAsync(q.d_xq, Xq, sizeof(double) * (size_t)(Nq * m->D), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -100;
         if (!rc) rc = launch_iota(q.d_sorted_item, Nq, c->stream);
-        if (!rc) rc = build_strip_tasks(&q, c->stream);
-        if (!rc) rc = launch_items(&q, *th, c->stream);
+        if (!rc) rc = PMK_BY_DTYPE(m, build_strip_tasks(&q, c->stream));
+        if (!rc) rc = PMK_BY_DTYPE(m, launch_items(&q, *th, c->stream));
         if (!rc && (hipMemcpyAsync(mu, q.d_u, sizeof(double) * (size_t)Nq, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                     hipMemcpyAsync(var, q.d_v, sizeof(double) * (size_t)Nq, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                     hipStreamSynchronize(c->stream) != hipSuccess)) {
@@ -710,7 +752,7 @@ int pmk_query_plan(pmk_query *q, double radius, double delta)
         if ((rc = launch_sort_items(q, s))) return rc;
         PMK_HIP(hipMemcpyAsync(q->roff.data(), q->d_roff, sizeof(int64_t) * q->roff.size(), hipMemcpyDeviceToHost, s));
         PMK_HIP(hipStreamSynchronize(s));
-        if ((rc = build_strip_tasks(q, s))) return rc;
+        if ((rc = PMK_BY_DTYPE(m, build_strip_tasks(q, s)))) return rc;
     }
     c->toc("plan");
     q->planned = true;
@@ -742,7 +784,7 @@ int pmk_query_items(pmk_query *q, const pmk_kernel_desc *th)
     pmk_ctx *c = q->m->ctx;
     PMK_HIP(hipSetDevice(c->device));
     c->tic("items");
-    int rc = launch_items(q, *th, c->stream);
+    int rc = PMK_BY_DTYPE(q->m, launch_items(q, *th, c->stream));
     c->toc("items");
     return rc;
 }

@@ -21,6 +21,7 @@
 #include "pmk_mfma.h"
 
 namespace pmk {
+namespace PMK_NS {
 
 constexpr int LDT = TILE + 1;   // LDS leading dimension of the diagonal tile (row access conflict-free)
 constexpr int PF_CHOL = 4;      // I-operand prefetch depth (k-steps) of the panel GEMM; must divide TILE/4
@@ -35,32 +36,25 @@ constexpr int SB = 32;          // sub-block of the in-LDS potrf and of the TRSM
 // quadrant of the LDS tile: rows [32 (s&1), +32) x columns [64 + 32 (s>>1), +32)
 __device__ __forceinline__ int ninv_lds(int s, int i, int c) { return (32 * (s & 1) + i) + (64 + 32 * (s >> 1) + c) * LDT; }
 
-__device__ __forceinline__ double readlane_f64(double x, int l)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
-    return __hiloint2double(hi, lo);
-}
-
 // Fused kernel-matrix build (K1 folded into the factorisation): entry (i, j) of U = K + sigma2 I of a
 // patch, evaluated from the resident coordinates exactly as constructkernelmatrix! + the diagonal update
 // do (row point first for i >= j, mirrored above; src/RKHS/RKHS.jl:21-31, mixtureGP.jl:102-104), with the
 // identity padding of the slab.  FUSE = 0 reads the value kmat_slab_kernel wrote instead.
 template <int D, int FAM>
 struct TileSource {
-    const double *xs;     // SoA coordinates of the patch
+    const real *xs;     // SoA coordinates of the patch
     int64_t ld;
     int n;
-    double sigma2;
+    real sigma2;
     pmk_kernel_desc th;
-    __device__ __forceinline__ void point(int i, double *p) const
+    __device__ __forceinline__ void point(int i, real *p) const
     {
 #pragma unroll
         for (int d = 0; d < D; ++d) p[d] = xs[(int64_t)d * ld + i];
     }
-    __device__ __forceinline__ double value(int i, const double *pi, int j, const double *pj) const
+    __device__ __forceinline__ real value(int i, const real *pi, int j, const real *pj) const
     {
-        double v = (i >= j) ? kern_eval<D, FAM>(th, pi, pj) : kern_eval<D, FAM>(th, pj, pi);
+        real v = (i >= j) ? kern_eval<D, FAM, real>(th, pi, pj) : kern_eval<D, FAM, real>(th, pj, pi);
         v = (i == j) ? v + sigma2 : v;
         const bool inside = i < n && j < n;
         return inside ? v : ((i == j) ? 1.0 : 0.0);
@@ -71,25 +65,25 @@ struct TileSource {
 // diagonal block
 // ---------------------------------------------------------------------------------------------
 template <int D, int FAM, int FUSE>
-__global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restrict__ descs, double *__restrict__ A,
-                                                        double *__restrict__ ninv, const double *__restrict__ y,
-                                                        const double *__restrict__ ytmp, double *__restrict__ z,
+__global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restrict__ descs, real *__restrict__ A,
+                                                        real *__restrict__ ninv, const real *__restrict__ y,
+                                                        const real *__restrict__ ytmp, real *__restrict__ z,
                                                         int32_t *__restrict__ info, int k,
-                                                        const double *__restrict__ x, pmk_kernel_desc th, double sigma2,
+                                                        const real *__restrict__ x, pmk_kernel_desc th, double sigma2,
                                                         int skip)
 {
     const PatchDesc pd = descs[blockIdx.x];
     if (k >= pd.nt) return;
-    __shared__ double T[TILE * LDT];
-    __shared__ double rhs[2 * TILE];
+    __shared__ real T[TILE * LDT];
+    __shared__ real rhs[2 * TILE];
     __shared__ int s_bad;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = wave >> 1, g = wave & 1;          // 64-row half, 64-column half of the tile
-    double *S = A + pd.aoff;
+    real *S = A + pd.aoff;
     const int64_t ld = pd.ld;
     const int64_t d0 = (int64_t)k * TILE;
-    double *Akk = S + d0 + d0 * ld;
+    real *Akk = S + d0 + d0 * ld;
     if (tid == 0) s_bad = 0;
 
     // ---- T = A[kk] - L[k,k-1] L[k,k-1]^T   (older block columns were applied by the look-ahead
@@ -98,7 +92,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
         WaveTile<2, 2> acc;
         acc.zero();
         if (k > 0 && !(skip & 16)) {
-            const double *Lk = S + d0 + (d0 - TILE) * ld;      // L[k, k-1]: 128 x 128
+            const real *Lk = S + d0 + (d0 - TILE) * ld;      // L[k, k-1]: 128 x 128
             gemm_nt<2, 2, PF_DIAG>(acc, Lk + 64 * g, ld, Lk + 64 * h, ld, TILE, lane);
         }
 #pragma unroll
@@ -107,17 +101,17 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int pj = 0; pj < 2; ++pj) {
-                    const int cl = 64 * g + 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * q) + (fi & 1);
+                    const int cl = 64 * g + tile_i(fi, lane, q);
                     const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
-                    double2_t a;
+                    real2_t a;
                     if (FUSE && k == 0) {          // first tile: nothing was written to the slab, evaluate K here
-                        const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, sigma2, th};
-                        double pc[D], pr0[D], pr1[D];
+                        const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
+                        real pc[D], pr0[D], pr1[D];
                         src.point(cl, pc); src.point(rl, pr0); src.point(rl + 1, pr1);
                         a[0] = src.value(rl, pr0, cl, pc);
                         a[1] = src.value(rl + 1, pr1, cl, pc);
                     } else {
-                        a = *reinterpret_cast<const double2_t *>(Akk + rl + (int64_t)cl * ld);
+                        a = *reinterpret_cast<const real2_t *>(Akk + rl + (int64_t)cl * ld);
                     }
                     T[rl + cl * LDT] = a[0] - acc.f[fi][2 * pj][q];
                     T[rl + 1 + cl * LDT] = a[1] - acc.f[fi][2 * pj + 1][q];
@@ -126,17 +120,17 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
     // ---- forward-solve right-hand side: y_k - L[k,0:k-1] z (look-ahead) - L[k,k-1] z_{k-1}
     {
         const int row = tid & 127, half = tid >> 7;
-        double s = 0.0;
+        real s = 0.0;
         if (k > 0) {
-            const double *Lr = S + d0 + row + (d0 - TILE + 64 * half) * ld;
-            const double *zz = z + pd.yoff + d0 - TILE + 64 * half;
+            const real *Lr = S + d0 + row + (d0 - TILE + 64 * half) * ld;
+            const real *zz = z + pd.yoff + d0 - TILE + 64 * half;
             for (int c = 0; c < 64; ++c) s += Lr[(int64_t)c * ld] * zz[c];
         }
         rhs[tid] = s;
     }
     __syncthreads();
     if (tid < TILE) {
-        const double base = (k == 0) ? y[pd.yoff + tid] : ytmp[pd.yoff + d0 + tid];
+        const real base = (k == 0) ? y[pd.yoff + tid] : ytmp[pd.yoff + d0 + tid];
         rhs[tid] = base - (rhs[tid] + rhs[tid + TILE]);
     }
 
@@ -148,10 +142,10 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
     //      sequences: the 128 pivots are a serial latency chain, this is its critical path).
     __syncthreads();
     {
-        __shared__ double col[TILE];
-        __shared__ double sdiag;
+        __shared__ real col[TILE];
+        __shared__ real sdiag;
         const int tr = tid & 15, tc = tid >> 4;
-        double a_[8][8];
+        real a_[8][8];
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -161,30 +155,27 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
         for (int j = 0; j < ((skip & 1) ? 0 : TILE); ++j) {
             const int bj = j >> 4;
             if (tc == (j & 15)) {
-                double d = sdiag;
+                real d = sdiag;
                 if (!(d > 0.0)) {                         // not positive definite (or NaN): record, keep going
                     if (tr == 0 && s_bad == 0) s_bad = k * TILE + j + 1;
                     d = 1.0;
                 }
-                double rs = __builtin_amdgcn_rsq(d);
-                const double hd = 0.5 * d;
-                rs = __builtin_fma(rs, __builtin_fma(-hd * rs, rs, 0.5), rs);
-                rs = __builtin_fma(rs, __builtin_fma(-hd * rs, rs, 0.5), rs);
-                const double ljj = d * rs;
+                const real rs = rsqrt_real(d);
+                const real ljj = d * rs;
 #pragma unroll
                 for (int b2 = 0; b2 < 8; ++b2)
                     if (b2 == bj) {
 #pragma unroll
                         for (int a = 0; a < 8; ++a) {
                             const int r = tr + 16 * a;
-                            const double v = (r > j) ? a_[a][b2] * rs : ((r == j) ? ljj : a_[a][b2]);
+                            const real v = (r > j) ? a_[a][b2] * rs : ((r == j) ? ljj : a_[a][b2]);
                             a_[a][b2] = v;
                             col[r] = (r > j) ? v : 0.0;
                         }
                     }
             }
             __syncthreads();
-            double cr[8], cc[8];
+            real cr[8], cc[8];
 #pragma unroll
             for (int a = 0; a < 8; ++a) { cr[a] = col[tr + 16 * a]; cc[a] = col[tc + 16 * a]; }
 #pragma unroll
@@ -215,10 +206,10 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
     // ---- negated inverses of the four 32 x 32 diagonal blocks: wave w inverts block w, one thread per column
     if (lane < SB && !(skip & 2)) {
         const int o = SB * wave, c = lane;
-        double x[SB];
+        real x[SB];
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
-            double sacc = (i == c) ? 1.0 : 0.0;
+            real sacc = (i == c) ? 1.0 : 0.0;
 #pragma unroll
             for (int l = 0; l < i; ++l) sacc -= T[(o + i) + (o + l) * LDT] * x[l];
             x[i] = sacc / T[(o + i) + (o + i) * LDT];
@@ -234,7 +225,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
         const int i = e & 127, c = e >> 7;
         Akk[i + (int64_t)c * ld] = (i >= c) ? T[i + c * LDT] : 0.0;
     }
-    double *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
+    real *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
     for (int e = tid; e < 4 * SB * SB; e += 256) {
         const int s = e >> 10, i = e & 31, c = (e >> 5) & 31;
         Ni[e] = (i >= c) ? T[ninv_lds(s, i, c)] : 0.0;
@@ -243,13 +234,13 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
     for (int s = 0; s < ((skip & 8) ? 0 : 4); ++s) {
         if (tid < SB) {
             const int r = SB * s + tid;
-            double v = rhs[r];
+            real v = rhs[r];
             for (int c = 0; c < SB * s; ++c) v -= T[r + c * LDT] * rhs[TILE + c];
             rhs[r] = v;
         }
         __syncthreads();
         if (tid < SB) {
-            double v = 0.0;
+            real v = 0.0;
             for (int c = 0; c < SB; ++c) v -= T[ninv_lds(s, tid, c)] * rhs[SB * s + c];    // D^-1 r = -(Ninv r)
             rhs[TILE + SB * s + tid] = v;
         }
@@ -264,10 +255,10 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
 // independent (no LDS, no barrier) and two workgroups share a CU (2 waves per SIMD)
 // ---------------------------------------------------------------------------------------------
 template <int D, int FAM, int FUSE>
-__global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__restrict__ descs, double *__restrict__ A,
-                                                            const double *__restrict__ ninv, const double *__restrict__ y,
-                                                            const double *__restrict__ z, double *__restrict__ ytmp, int k,
-                                                            const double *__restrict__ x, pmk_kernel_desc th, double sigma2)
+__global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__restrict__ descs, real *__restrict__ A,
+                                                            const real *__restrict__ ninv, const real *__restrict__ y,
+                                                            const real *__restrict__ z, real *__restrict__ ytmp, int k,
+                                                            const real *__restrict__ x, pmk_kernel_desc th, double sigma2)
 {
     // logical (block row, patch) from the XCD-aware id: all workgroups of a patch land on one XCD and
     // share the I-operand (block row k of L) through that XCD's L2
@@ -275,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
     const int bx = lid % gridDim.x;
     const PatchDesc pd = descs[lid / gridDim.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double *S = A + pd.aoff;
+    real *S = A + pd.aoff;
     const int64_t ld = pd.ld;
     const int64_t c0 = (int64_t)k * TILE;
 
@@ -289,20 +280,20 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
             WaveTile<2, 2> acc;
             acc.zero();
             if (k > 0) gemm_nt<2, 2, PF_DIAG>(acc, S + t0 + 64 * g, ld, S + t0 + 64 * h, ld, k * TILE, lane);
-            double *Att = S + t0 + t0 * ld;
-            const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, sigma2, th};
+            real *Att = S + t0 + t0 * ld;
+            const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int pj = 0; pj < 2; ++pj) {
-                        const int cl = 64 * g + 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * q) + (fi & 1);
+                        const int cl = 64 * g + tile_i(fi, lane, q);
                         const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
-                        double2_t *p = reinterpret_cast<double2_t *>(Att + rl + (int64_t)cl * ld);
-                        double2_t a;
+                        real2_t *p = reinterpret_cast<real2_t *>(Att + rl + (int64_t)cl * ld);
+                        real2_t a;
                         if (FUSE) {
-                            double pc[D], pr0[D], pr1[D];
+                            real pc[D], pr0[D], pr1[D];
                             const int gc = (int)t0 + cl, gr = (int)t0 + rl;
                             src.point(gc, pc); src.point(gr, pr0); src.point(gr + 1, pr1);
                             a[0] = src.value(gr, pr0, gc, pc);
@@ -317,19 +308,19 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
         }
         if (h == 0 && g == 1) {
             // the wave without a GEMM sub-tile does the forward-solve piece: two rows per lane
-            const double *Lr = S + t0 + 2 * lane;
-            const double *zz = z + pd.yoff;
-            double2_t s0 = {0.0, 0.0}, s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, s3 = {0.0, 0.0};
+            const real *Lr = S + t0 + 2 * lane;
+            const real *zz = z + pd.yoff;
+            real2_t s0 = {0.0, 0.0}, s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, s3 = {0.0, 0.0};
             for (int c = 0; c < k * TILE; c += 4) {
-                const double2_t a0 = *reinterpret_cast<const double2_t *>(Lr + (int64_t)c * ld);
-                const double2_t a1 = *reinterpret_cast<const double2_t *>(Lr + (int64_t)(c + 1) * ld);
-                const double2_t a2 = *reinterpret_cast<const double2_t *>(Lr + (int64_t)(c + 2) * ld);
-                const double2_t a3 = *reinterpret_cast<const double2_t *>(Lr + (int64_t)(c + 3) * ld);
+                const real2_t a0 = *reinterpret_cast<const real2_t *>(Lr + (int64_t)c * ld);
+                const real2_t a1 = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + 1) * ld);
+                const real2_t a2 = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + 2) * ld);
+                const real2_t a3 = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + 3) * ld);
                 s0 += a0 * zz[c]; s1 += a1 * zz[c + 1]; s2 += a2 * zz[c + 2]; s3 += a3 * zz[c + 3];
             }
-            const double2_t sum = (s0 + s1) + (s2 + s3);
-            const double2_t yy = *reinterpret_cast<const double2_t *>(y + pd.yoff + t0 + 2 * lane);
-            *reinterpret_cast<double2_t *>(ytmp + pd.yoff + t0 + 2 * lane) = yy - sum;
+            const real2_t sum = (s0 + s1) + (s2 + s3);
+            const real2_t yy = *reinterpret_cast<const real2_t *>(y + pd.yoff + t0 + 2 * lane);
+            *reinterpret_cast<real2_t *>(ytmp + pd.yoff + t0 + 2 * lane) = yy - sum;
         }
         return;
     }
@@ -337,25 +328,25 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
     // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per
     // workgroup; the loads are in flight while the GEMM below runs
     if ((int64_t)(k + 1 + bx) * TILE >= pd.ld) return;      // whole workgroup: ld is a multiple of TILE
-    __shared__ double tri[TRI_LDS_DOUBLES];
+    __shared__ real tri[TRI_LDS_DOUBLES];
     stage_tri_operands(tri, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
     __syncthreads();
     const int64_t r0 = (int64_t)(k + 1 + bx) * TILE + 32 * wave;
-    double *out = S + r0 + 2 * (lane & 15) + (c0 + 2 * (lane >> 4)) * ld;   // element (fi = 0, q = 0)
+    real *out = S + r0 + 2 * (lane & 15) + c0 * ld;   // rows of this lane, first column of the block column
 
     // acc starts as -A[rows, block column k]; the GEMM adds L[rows,0:k] L[k,0:k]^T, so acc = -T
     WaveTile<4, 1> acc;   // I = the 128 columns of block column k, J = 32 rows
     if (FUSE) {
-        const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, sigma2, th};
+        const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
         const int gr = (int)r0 + 2 * (lane & 15);
-        double pr0[D], pr1[D];
+        real pr0[D], pr1[D];
         src.point(gr, pr0); src.point(gr + 1, pr1);
 #pragma unroll
         for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int gc = (int)c0 + 2 * (lane >> 4) + 32 * (fi >> 1) + 8 * q + (fi & 1);
-                double pc[D];
+                const int gc = (int)c0 + tile_i(fi, lane, q);
+                real pc[D];
                 src.point(gc, pc);
                 acc.f[fi][0][q] = -src.value(gr, pr0, gc, pc);
                 acc.f[fi][1][q] = -src.value(gr + 1, pr1, gc, pc);
@@ -365,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
         for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cl = 32 * (fi >> 1) + 8 * q + (fi & 1);
-                const double2_t a = *reinterpret_cast<const double2_t *>(out + cl * ld);
+                const int cl = tile_i(fi, lane, q);
+                const real2_t a = *reinterpret_cast<const real2_t *>(out + cl * ld);
                 acc.f[fi][0][q] = -a[0];
                 acc.f[fi][1][q] = -a[1];
             }
@@ -378,11 +369,11 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
     for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int cl = 32 * (fi >> 1) + 8 * q + (fi & 1);
-            double2_t o;
+            const int cl = tile_i(fi, lane, q);
+            real2_t o;
             o[0] = acc.f[fi][0][q];
             o[1] = acc.f[fi][1][q];
-            *reinterpret_cast<double2_t *>(out + cl * ld) = o;
+            *reinterpret_cast<real2_t *>(out + cl * ld) = o;
         }
 }
 
@@ -390,23 +381,23 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
 // c = L^-T z, one workgroup (16 waves) per patch, block rows from the last to the first
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void chol_backsolve_kernel(const PatchDesc *__restrict__ descs,
-                                                              const double *__restrict__ A, const double *__restrict__ ninv,
-                                                              const double *__restrict__ z, double *__restrict__ cvec)
+                                                              const real *__restrict__ A, const real *__restrict__ ninv,
+                                                              const real *__restrict__ z, real *__restrict__ cvec)
 {
     const PatchDesc pd = descs[blockIdx.x];
-    extern __shared__ double sm[];
-    double *cs = sm;                  // ld : the solution so far
-    double *r = sm + pd.ld;           // TILE
+    extern __shared__ real sm[];
+    real *cs = sm;                  // ld : the solution so far
+    real *r = sm + pd.ld;           // TILE
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double *S = A + pd.aoff;
+    const real *S = A + pd.aoff;
     const int64_t ld = pd.ld;
     for (int k = pd.nt - 1; k >= 0; --k) {
         const int64_t d0 = (int64_t)k * TILE;
         // r[col] = z_k[col] - sum_{i >= d0 + TILE} L[i, d0 + col] c[i]: one wave per column, coalesced rows
         const int64_t i0 = d0 + TILE;
         for (int cc = wave; cc < TILE; cc += 16) {
-            const double *col = S + (d0 + cc) * ld;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            const real *col = S + (d0 + cc) * ld;
+            real s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             int64_t i = i0 + lane;
             for (; i + 192 < ld; i += 256) {
                 s0 += col[i] * cs[i];
@@ -415,25 +406,25 @@ __global__ __launch_bounds__(1024) void chol_backsolve_kernel(const PatchDesc *_
                 s3 += col[i + 192] * cs[i + 192];
             }
             for (; i < ld; i += 64) s0 += col[i] * cs[i];
-            double s = (s0 + s1) + (s2 + s3);
+            real s = (s0 + s1) + (s2 + s3);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
             if (lane == 0) r[cc] = z[pd.yoff + d0 + cc] - s;
         }
         __syncthreads();
         // c_k = L[kk]^-T r by block backward substitution with the negated inverted 32 x 32 blocks
-        const double *Lkk = S + d0 + d0 * ld;
-        const double *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
+        const real *Lkk = S + d0 + d0 * ld;
+        const real *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
         for (int s = 3; s >= 0; --s) {
             if (tid < SB) {
                 const int col = SB * s + tid;
-                double v = r[col];
+                real v = r[col];
                 for (int i = SB * (s + 1); i < TILE; ++i) v -= Lkk[i + (int64_t)col * ld] * cs[d0 + i];
                 r[col] = v;
             }
             __syncthreads();
             if (tid < SB) {
-                double v = 0.0;
+                real v = 0.0;
                 for (int i = tid; i < SB; ++i) v -= Ni[1024 * s + i + 32 * tid] * r[SB * s + i];   // D^-T r
                 cs[d0 + SB * s + tid] = v;
             }
@@ -451,11 +442,11 @@ static int launch_cholesky_T(pmk_model *m, hipStream_t s, int64_t p0, int64_t np
     PMK_HIP(hipMemsetAsync(m->d_info + p0, 0, sizeof(int32_t) * np, s));
     pmk_ctx *c = m->ctx;
     c->panel_n = 0;
-    double *ytmp = m->d_c;      // the weight vector is free until the back substitution: scratch for y - L z
+    real *ytmp = (real *)m->d_c;      // the weight vector is free until the back substitution: scratch for y - L z
     static const int dbg_skip = getenv("PMK_DBG_DIAG_SKIP") ? atoi(getenv("PMK_DBG_DIAG_SKIP")) : 0;   // timing experiments only
     for (int k = 0; k < m->max_nt; ++k) {
-        hipLaunchKernelGGL((chol_diag_kernel<D, FAM, FUSE>), dim3((unsigned)np), dim3(256), 0, s, m->d_desc + p0, m->d_a,
-                           m->d_inv, m->d_y, ytmp, m->d_z, m->d_info + p0, k, m->d_x, m->th, m->sigma2, dbg_skip);
+        hipLaunchKernelGGL((chol_diag_kernel<D, FAM, FUSE>), dim3((unsigned)np), dim3(256), 0, s, m->d_desc + p0, (real *)m->d_a,
+                           (real *)m->d_inv, (real *)m->d_y, ytmp, (real *)m->d_z, m->d_info + p0, k, (real *)m->d_x, m->th, m->sigma2, dbg_skip);
         const int below = m->max_nt - k - 1;
         if (below > 0) {
             const bool fine = c->timers >= 2;
@@ -470,7 +461,7 @@ static int launch_cholesky_T(pmk_model *m, hipStream_t s, int64_t p0, int64_t np
             }
             // grid.x = block rows below + 1 look-ahead workgroup
             hipLaunchKernelGGL((chol_panel_kernel<D, FAM, FUSE>), dim3((unsigned)(below + 1), (unsigned)np), dim3(256), 0, s,
-                               m->d_desc + p0, m->d_a, m->d_inv, m->d_y, m->d_z, ytmp, k, m->d_x, m->th, m->sigma2);
+                               m->d_desc + p0, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_y, (real *)m->d_z, ytmp, k, (real *)m->d_x, m->th, m->sigma2);
             if (fine) {
                 PMK_HIP(hipEventRecord(c->panel_ev[(size_t)k].second, s));
                 c->panel_n = k + 1;
@@ -496,24 +487,24 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, int fus
 }
 
 // -(L[ss])^-1 of every 32 x 32 diagonal block of factors that were loaded from the host (pmk_model_load)
-__global__ __launch_bounds__(64) void ninv_from_slab_kernel(const PatchDesc *__restrict__ descs, const double *__restrict__ A,
-                                                            double *__restrict__ ninv)
+__global__ __launch_bounds__(64) void ninv_from_slab_kernel(const PatchDesc *__restrict__ descs, const real *__restrict__ A,
+                                                            real *__restrict__ ninv)
 {
     const PatchDesc pd = descs[blockIdx.y];
     const int blk = blockIdx.x;                 // 32-block index along the diagonal
     if (blk >= 4 * pd.nt) return;
     const int c = threadIdx.x;
     if (c >= SB) return;
-    const double *Dg = A + pd.aoff + (int64_t)SB * blk + (int64_t)SB * blk * pd.ld;
-    double x[SB];
+    const real *Dg = A + pd.aoff + (int64_t)SB * blk + (int64_t)SB * blk * pd.ld;
+    real x[SB];
 #pragma unroll
     for (int i = 0; i < SB; ++i) {
-        double sacc = (i == c) ? 1.0 : 0.0;
+        real sacc = (i == c) ? 1.0 : 0.0;
 #pragma unroll
         for (int l = 0; l < i; ++l) sacc -= Dg[i + (int64_t)l * pd.ld] * x[l];
         x[i] = sacc / Dg[i + (int64_t)i * pd.ld];
     }
-    double *out = ninv + pd.ioff + (int64_t)blk * (SB * SB);
+    real *out = ninv + pd.ioff + (int64_t)blk * (SB * SB);
 #pragma unroll
     for (int i = 0; i < SB; ++i) out[i + SB * c] = (i >= c) ? -x[i] : 0.0;
 }
@@ -521,18 +512,19 @@ __global__ __launch_bounds__(64) void ninv_from_slab_kernel(const PatchDesc *__r
 int launch_ninv_from_slabs(pmk_model *m, hipStream_t s)
 {
     hipLaunchKernelGGL(ninv_from_slab_kernel, dim3((unsigned)(4 * m->max_nt), (unsigned)m->P), dim3(64), 0, s, m->d_desc,
-                       m->d_a, m->d_inv);
+                       (real *)m->d_a, (real *)m->d_inv);
     PMK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 {
-    const size_t lds = sizeof(double) * ((size_t)m->max_nt * TILE + TILE);
-    hipLaunchKernelGGL(chol_backsolve_kernel, dim3((unsigned)np), dim3(1024), lds, s, m->d_desc + p0, m->d_a, m->d_inv,
-                       m->d_z, m->d_c);
+    const size_t lds = sizeof(real) * ((size_t)m->max_nt * TILE + TILE);
+    hipLaunchKernelGGL(chol_backsolve_kernel, dim3((unsigned)np), dim3(1024), lds, s, m->d_desc + p0, (real *)m->d_a, (real *)m->d_inv,
+                       (real *)m->d_z, (real *)m->d_c);
     PMK_HIP(hipGetLastError());
     return 0;
 }
 
+}  // namespace PMK_NS
 }  // namespace pmk

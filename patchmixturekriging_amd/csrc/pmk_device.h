@@ -63,119 +63,130 @@ __device__ __forceinline__ double div3_cr(double x)
 
 // evalkernel(tau, theta): src/RKHS/kernel.jl:299-381 of the reference.
 // FAM != 0 fixes the family at compile time (the hot kernels are instantiated for Spline34 so the
-// unrolled tile loops carry one straight-line formula instead of the whole switch).
-template <int FAM = 0>
-__device__ __forceinline__ double profile(const pmk_kernel_desc &th, double tau)
+// unrolled tile loops carry one straight-line formula instead of the whole switch).  R = double is the
+// parity path (operation order of the reference, correctly rounded tmp^6 and /3); R = float is the fp32
+// configuration, which has no reference semantics (the reference is Float64-only) and uses plain float ops.
+template <int FAM = 0, typename R = double>
+__device__ __forceinline__ R profile(const pmk_kernel_desc &th, R tau)
 {
+    constexpr bool F64 = sizeof(R) == 8;
+    const R p0 = (R)th.p[0], p1 = (R)th.p[1];
     switch (FAM ? FAM : th.family) {
     case PMK_SPLINE34: {
-        double r = tau * th.p[0];
-        double t = 1.0 - r;
+        R r = tau * p0;
+        R t = (R)1 - r;
         // branch-free form of `if sign(tmp) < 0 return 0`: outside the support evaluate at r = 1, t = 0,
         // which gives exactly +0.0 (selects, so the unrolled tile loops stay straight-line code)
-        const bool outside = t < 0.0;
-        r = outside ? 1.0 : r;
-        t = outside ? 0.0 : t;
-        const double t6 = pow6_cr(t);                        // tmp^6
-        return div3_cr(((35.0 * (r * r) + 18.0 * r) + 3.0) * t6);
+        const bool outside = t < (R)0;
+        r = outside ? (R)1 : r;
+        t = outside ? (R)0 : t;
+        if constexpr (F64) {
+            const double t6 = pow6_cr(t);                    // tmp^6
+            return div3_cr(((35.0 * (r * r) + 18.0 * r) + 3.0) * t6);
+        } else {
+            const R t2 = t * t;
+            return ((((R)35 * (r * r) + (R)18 * r) + (R)3) * (t2 * t2 * t2)) * (R)(1.0 / 3.0);
+        }
     }
     case PMK_SPLINE12: {
-        double r = tau * th.p[0];
-        double t = 1.0 - r;
-        if (t < 0.0) return 0.0;
-        return (3.0 * r + 1.0) * (t * t * t);
+        R r = tau * p0;
+        R t = (R)1 - r;
+        if (t < (R)0) return (R)0;
+        return ((R)3 * r + (R)1) * (t * t * t);
     }
     case PMK_SPLINE32: {
-        double r = tau * th.p[0];
-        double t = 1.0 - r;
-        if (t < 0.0) return 0.0;
-        return (4.0 * r + 1.0) * pow4_cr(t);               // tmp^4
+        R r = tau * p0;
+        R t = (R)1 - r;
+        if (t < (R)0) return (R)0;
+        if constexpr (F64) return (4.0 * r + 1.0) * pow4_cr(t);               // tmp^4
+        else { const R t2 = t * t; return ((R)4 * r + (R)1) * (t2 * t2); }
     }
     case PMK_GAUSSIAN:
-        return exp((-th.p[0]) * (tau * tau));
+        return exp((-p0) * (tau * tau));
     case PMK_RQ: {
-        double s = sqrt(th.p[0] + tau * tau);
-        double sa = sqrt(th.p[0]);
+        R s = sqrt(p0 + tau * tau);
+        R sa = sqrt(p0);
         return (sa * sa * sa) / (s * s * s);
     }
     case PMK_TRQ: {
-        double s = sqrt(th.p[0] + tau * tau);
-        double sa = sqrt(th.p[0]);
-        return (th.p[1] * (sa * sa * sa)) / (s * s * s);
+        R s = sqrt(p0 + tau * tau);
+        R sa = sqrt(p0);
+        return (p1 * (sa * sa * sa)) / (s * s * s);
     }
     case PMK_MODSQEXP:
-        return exp((-th.p[0]) * (tau * tau)) * cos(th.p[1] * tau);
+        return exp((-p0) * (tau * tau)) * cos(p1 * tau);
     default:
-        return __builtin_nan("");
+        return (R)__builtin_nan("");
     }
 }
 
 // Brownian-bridge scalar kernels: kernel.jl:156-158, :218-225, :168-174, :176-193, :256-263
-__device__ __forceinline__ double bb_scalar(const pmk_kernel_desc &th, double x, double z)
+template <typename R = double>
+__device__ __forceinline__ R bb_scalar(const pmk_kernel_desc &th, R x, R z)
 {
     if (th.flags & PMK_FLAG_SEMIINF) {
-        x = x / (2.0 * (1.0 + x));
-        z = z / (2.0 * (1.0 + z));
+        x = x / ((R)2 * ((R)1 + x));
+        z = z / ((R)2 * ((R)1 + z));
     }
     switch (th.family) {
     case PMK_BB10:
         return fmin(x, z) - x * z;
     case PMK_BB20: {
-        const double m16 = -1.0 / 6.0;
-        if (z < x) return ((m16 * z) * (1.0 - x)) * ((x * x + z * z) - 2.0 * x);
-        return ((m16 * x) * (1.0 - z)) * ((x * x + z * z) - 2.0 * z);
+        const R m16 = (R)(-1.0 / 6.0);
+        if (z < x) return ((m16 * z) * ((R)1 - x)) * ((x * x + z * z) - (R)2 * x);
+        return ((m16 * x) * ((R)1 - z)) * ((x * x + z * z) - (R)2 * z);
     }
     case PMK_BB1EPS: {
-        double e = th.p[0];
-        double den = e * sinh(e);
-        double num = sinh(e * fmin(x, z)) * sinh(e * (1.0 - fmax(x, z)));
+        R e = (R)th.p[0];
+        R den = e * sinh(e);
+        R num = sinh(e * fmin(x, z)) * sinh(e * ((R)1 - fmax(x, z)));
         return num / den;
     }
     case PMK_BB2EPS: {
-        double e = th.p[0];
-        double s = x + z;
-        double mn = fmin(x, z), mx = fmax(x, z), ad = fabs(x - z);
-        double num = exp((-e) * s);
-        double em1 = exp(2.0 * e) - 1.0;
-        double den = (4.0 * (e * e * e)) * (em1 * em1);
-        double mult = num / den;
-        double t1 = exp(2.0 * e) * ((2.0 * e - e * s) - 1.0);
-        double t2 = exp(4.0 * e) * (e * s + 1.0);
-        double t3 = exp((2.0 * e) * ((1.0 + x) + z)) * ((2.0 * e - e * s) + 1.0);
-        double t4 = exp((2.0 * e) * s) * (e * s - 1.0);
-        double t5 = exp((2.0 * e) * (2.0 + mn)) * ((-e) * ad - 1.0);
-        double t6 = exp((2.0 * e) * mx) * ((-e) * ad + 1.0);
-        double t7 = exp((2.0 * e) * (1.0 + mn)) * ((1.0 - 2.0 * e) + e * ad);
-        double t8 = exp((2.0 * e) * (1.0 + mx)) * ((1.0 + 2.0 * e) - e * ad);
+        R e = (R)th.p[0];
+        R s = x + z;
+        R mn = fmin(x, z), mx = fmax(x, z), ad = fabs(x - z);
+        R num = exp((-e) * s);
+        R em1 = exp((R)2 * e) - (R)1;
+        R den = ((R)4 * (e * e * e)) * (em1 * em1);
+        R mult = num / den;
+        R t1 = exp((R)2 * e) * (((R)2 * e - e * s) - (R)1);
+        R t2 = exp((R)4 * e) * (e * s + (R)1);
+        R t3 = exp(((R)2 * e) * (((R)1 + x) + z)) * (((R)2 * e - e * s) + (R)1);
+        R t4 = exp(((R)2 * e) * s) * (e * s - (R)1);
+        R t5 = exp(((R)2 * e) * ((R)2 + mn)) * ((-e) * ad - (R)1);
+        R t6 = exp(((R)2 * e) * mx) * ((-e) * ad + (R)1);
+        R t7 = exp(((R)2 * e) * ((R)1 + mn)) * (((R)1 - (R)2 * e) + e * ad);
+        R t8 = exp(((R)2 * e) * ((R)1 + mx)) * (((R)1 + (R)2 * e) - e * ad);
         return mult * (((((((t1 + t2) + t3) + t4) + t5) + t6) + t7) + t8);
     }
     default:
-        return __builtin_nan("");
+        return (R)__builtin_nan("");
     }
 }
 
 // evalkernel(p, q, theta) with p, q in registers.  Stationary: tau = norm(p-q) as a sequential
 // sum of squares and one sqrt (kernel.jl:277-287); Brownian bridge: product over dimensions
 // (kernel.jl:196-206).
-template <int D, int FAM = 0>
-__device__ __forceinline__ double kern_eval(const pmk_kernel_desc &th, const double *p, const double *q)
+template <int D, int FAM = 0, typename R = double>
+__device__ __forceinline__ R kern_eval(const pmk_kernel_desc &th, const R *p, const R *q)
 {
     const int fam = FAM ? FAM : th.family;
     if (fam >= PMK_BB10) {
-        double out = bb_scalar(th, p[0], q[0]);
+        R out = bb_scalar<R>(th, p[0], q[0]);
 #pragma unroll
-        for (int d = 1; d < D; ++d) out = out * bb_scalar(th, p[d], q[d]);
+        for (int d = 1; d < D; ++d) out = out * bb_scalar<R>(th, p[d], q[d]);
         return out;
     }
-    if (fam == PMK_MODSQEXP && D > 1) return __builtin_nan("");
-    double r0 = p[0] - q[0];
-    double s = r0 * r0;
+    if (fam == PMK_MODSQEXP && D > 1) return (R)__builtin_nan("");
+    R r0 = p[0] - q[0];
+    R s = r0 * r0;
 #pragma unroll
     for (int d = 1; d < D; ++d) {
-        double r = p[d] - q[d];
+        R r = p[d] - q[d];
         s = s + r * r;
     }
-    return profile<FAM>(th, sqrt(s));
+    return profile<FAM, R>(th, sqrt(s));
 }
 
 // dot(u, x) as the reference's short ddot: sequential multiply-add, no FMA
@@ -206,16 +217,4 @@ __device__ __forceinline__ double dot_seq(const double *u, const double *x)
 //     J index = 32 pj + 2 (l & 15) + ej
 //     I index = 32 pi + 2 ((l >> 4) + 4 q) + ei
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double4_t mfma64(double a_i, double b_j, double4_t c)
-{
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a_i, b_j, c, 0, 0, 0);
-}
-
-// operand pair load: base points at element (index0, k0) of a column-major matrix whose rows
-// are the fragment index; lane reads indices index0 + 2 rho, +1 at column k0 + (l >> 4)
-__device__ __forceinline__ double2_t load_pair(const double *base, int64_t ld, int lane)
-{
-    return *reinterpret_cast<const double2_t *>(base + 2 * (lane & 15) + (int64_t)(lane >> 4) * ld);
-}
-
 }  // namespace pmk

@@ -83,12 +83,14 @@ struct pmk_model {
     int max_nt = 0;
     std::vector<pmk::PatchDesc> desc;   // host copy
     pmk::PatchDesc *d_desc = nullptr;
-    double *d_x = nullptr;              // SoA coordinates
-    double *d_y = nullptr;              // targets (padded with 0)
-    double *d_z = nullptr;              // L^-1 y
-    double *d_c = nullptr;              // weights
-    double *d_a = nullptr;              // slabs
-    double *d_inv = nullptr;            // -(L[ss])^-1 for every 32 x 32 diagonal block of L
+    int dtype = PMK_F64;                // arithmetic type of the device path (element type of the buffers below)
+    size_t esz = 8;
+    void *d_x = nullptr;                // SoA coordinates
+    void *d_y = nullptr;                // targets (padded with 0)
+    void *d_z = nullptr;                // L^-1 y
+    void *d_c = nullptr;                // weights
+    void *d_a = nullptr;                // slabs
+    void *d_inv = nullptr;              // -(L[ss])^-1 for every 32 x 32 diagonal block of L
     int32_t *d_info = nullptr;          // per patch
     int64_t tot_a = 0, tot_x = 0, tot_y = 0, tot_inv = 0;
     bool fitted = false;
@@ -100,7 +102,7 @@ struct pmk_model {
     double *d_hv = nullptr, *d_hc = nullptr;   // heap order
     int32_t *d_pre = nullptr;                  // pre-order -> heap
     // prediction strip workspace
-    double *d_strip = nullptr;
+    void *d_strip = nullptr;
     int64_t strip_slots = 0;
 };
 
@@ -132,20 +134,28 @@ struct pmk_query {
 namespace pmk {
 
 // ---- launchers implemented in the .hip files (all enqueue on `s`) ----
-int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s,
-                               int64_t p0, int64_t np);
+// precision-generic kernels live in namespaces f64 / f32 (the same sources compiled twice)
+#define PMK_DECLARE_REAL_LAUNCHERS(NS)                                                                              \
+    namespace NS {                                                                                                   \
+    int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s,      \
+                                   int64_t p0, int64_t np);                                                          \
+    int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, int fuse);                              \
+    int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);                                       \
+    int launch_ninv_from_slabs(pmk_model *m, hipStream_t s);                                                         \
+    int build_strip_tasks(pmk_query *q, hipStream_t s);                                                              \
+    int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s);                                        \
+    }
+PMK_DECLARE_REAL_LAUNCHERS(f64)
+PMK_DECLARE_REAL_LAUNCHERS(f32)
+#define PMK_BY_DTYPE(m, CALL) ((m)->dtype == PMK_F32 ? pmk::f32::CALL : pmk::f64::CALL)
+
 int launch_kernel_matrix_dense(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
                                int64_t mcols, const double *d_zs, int64_t ldz, double *d_K, int64_t ldk,
                                bool symmetric, hipStream_t s);
-int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, int fuse);
-int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);
-int launch_ninv_from_slabs(pmk_model *m, hipStream_t s);
 int launch_iota(int32_t *d, int64_t n, hipStream_t s);
 int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_plan_fill(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_sort_items(pmk_query *q, hipStream_t s);
-int build_strip_tasks(pmk_query *q, hipStream_t s);
-int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s);
 int launch_mix(pmk_query *q, const pmk_kernel_desc &wth, int64_t q0, int64_t q1, hipStream_t s);
 int launch_query_mean(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
                       const double *d_c, int64_t nq, const double *d_xq, double *d_yq, hipStream_t s);

@@ -5,73 +5,6 @@
 
 namespace pmk {
 
-// =============================================================================================
-// K1: batched kernel-matrix build into the factorisation slabs.
-// Replaces the evalkernel double loop of constructkernelmatrix! (src/RKHS/RKHS.jl:21-31) and the
-// diagonal "+= sigma2" of fitmixtureGP! (src/RKHS/mixtureGP.jl:102-104).  HBM-write bound:
-// 8 * ld^2 / 2 bytes per patch (lower triangle; diagonal 64x64 tiles are written whole and exactly
-// symmetric).  One workgroup = one 64 x 64 tile, one thread = 4 contiguous rows x 4 columns, so a
-// 16-thread row group stores 512 contiguous bytes per column.  Padding rows/columns (index >= n) are
-// written as identity so the padded factorisation stays positive definite.
-// =============================================================================================
-template <int D, int FAM>
-__global__ __launch_bounds__(256) void kmat_slab_kernel(const PatchDesc *__restrict__ descs, const double *__restrict__ x,
-                                                        double *__restrict__ A, pmk_kernel_desc th, double sigma2)
-{
-    const PatchDesc pd = descs[blockIdx.y];
-    const int nt64 = pd.ld / 64;
-    const int ntiles = nt64 * (nt64 + 1) / 2;
-    const int t = blockIdx.x;
-    if (t >= ntiles) return;
-    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int i0 = ti * 64 + 4 * tx, j0 = tj * 64 + 4 * ty;
-    const double *xs = x + pd.xoff;
-    double xi[4][D], xj[4][D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const double4_t vi = *reinterpret_cast<const double4_t *>(xs + (int64_t)d * pd.ld + i0);
-        const double4_t vj = *reinterpret_cast<const double4_t *>(xs + (int64_t)d * pd.ld + j0);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { xi[a][d] = vi[a]; xj[a][d] = vj[a]; }
-    }
-    double *S = A + pd.aoff;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int j = j0 + b;
-        double4_t o;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int i = i0 + a;
-            double v;
-            if (i < pd.n && j < pd.n) {
-                v = (i >= j) ? kern_eval<D, FAM>(th, xi[a], xj[b]) : kern_eval<D, FAM>(th, xj[b], xi[a]);
-                if (i == j) v = v + sigma2;
-            } else {
-                v = (i == j) ? 1.0 : 0.0;
-            }
-            o[a] = v;
-        }
-        *reinterpret_cast<double4_t *>(S + i0 + (int64_t)j * pd.ld) = o;
-    }
-}
-
-template <int D>
-static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s, int64_t p0, int64_t np)
-{
-    const int nt64 = m->max_nt * (TILE / 64);
-    dim3 grid((unsigned)(nt64 * (nt64 + 1) / 2), (unsigned)np);
-    if (th.family == PMK_SPLINE34)
-        hipLaunchKernelGGL((kmat_slab_kernel<D, PMK_SPLINE34>), grid, dim3(256), 0, s, m->d_desc + p0, m->d_x, m->d_a, th, sigma2);
-    else
-        hipLaunchKernelGGL((kmat_slab_kernel<D, 0>), grid, dim3(256), 0, s, m->d_desc + p0, m->d_x, m->d_a, th, sigma2);
-    PMK_HIP(hipGetLastError());
-    return 0;
-}
-
 #define PMK_DISPATCH_D(D, CALL)                                    \
     switch (D) {                                                   \
     case 1: { constexpr int DD = 1; CALL; } break;                 \
@@ -80,14 +13,6 @@ static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double s
     case 4: { constexpr int DD = 4; CALL; } break;                 \
     default: set_error("unsupported input dimension %d (1..%d)", (int)(D), MAX_D); return -2; \
     }
-
-int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s,
-                               int64_t p0, int64_t np)
-{
-    int rc = 0;
-    PMK_DISPATCH_D(m->D, rc = launch_slab_D<DD>(m, th, sigma2, s, p0, np));
-    return rc;
-}
 
 // Dense n x m kernel matrix for the host API (constructkernelmatrix, RKHS.jl:4-34 and :95-110).
 // symmetric: entry (i,j) is evaluated as k(x_max, x_min) -- the lower-triangle value of the

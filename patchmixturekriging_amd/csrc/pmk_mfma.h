@@ -7,9 +7,10 @@
 // straight into registers and the four waves of a workgroup share the I-operand through L1.
 #pragma once
 
-#include "pmk_device.h"
+#include "pmk_real.h"
 
 namespace pmk {
+namespace PMK_NS {
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8) and every XCD has its own
 // L2.  xcd_remap() turns the hardware block id into a logical id such that each XCD works on one
@@ -23,47 +24,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// operand pair load: base points at element (index0, k0) of a column-major matrix whose rows are the
+// fragment index; lane reads indices index0 + 2 rho, +1 at column k0 + (l >> 4)
+__device__ __forceinline__ real2_t load_pair(const real *base, int64_t ld, int lane)
+{
+    return *reinterpret_cast<const real2_t *>(base + 2 * (lane & 15) + (int64_t)(lane >> 4) * ld);
+}
+
 template <int NPI, int NPJ>
 struct WaveTile {
-    double4_t f[2 * NPI][2 * NPJ];
+    real4_t f[2 * NPI][2 * NPJ];
     __device__ __forceinline__ void zero()
     {
 #pragma unroll
         for (int i = 0; i < 2 * NPI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2 * NPJ; ++j) f[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < 2 * NPJ; ++j) f[i][j] = real4_t{0, 0, 0, 0};
     }
 };
-
-template <int NPI, int NPJ>
-struct OperandRegs {
-    double2_t a[NPI];
-    double2_t b[NPJ];
-};
-
-template <int NPI, int NPJ>
-__device__ __forceinline__ void load_operands(OperandRegs<NPI, NPJ> &r, const double *opI, int64_t ldI,
-                                              const double *opJ, int64_t ldJ, int k, int lane)
-{
-#pragma unroll
-    for (int pi = 0; pi < NPI; ++pi) r.a[pi] = load_pair(opI + 32 * pi + (int64_t)k * ldI, ldI, lane);
-#pragma unroll
-    for (int pj = 0; pj < NPJ; ++pj) r.b[pj] = load_pair(opJ + 32 * pj + (int64_t)k * ldJ, ldJ, lane);
-}
-
-template <int NPI, int NPJ>
-__device__ __forceinline__ void mfma_step(WaveTile<NPI, NPJ> &t, const OperandRegs<NPI, NPJ> &r)
-{
-#pragma unroll
-    for (int pi = 0; pi < NPI; ++pi)
-#pragma unroll
-        for (int ei = 0; ei < 2; ++ei)
-#pragma unroll
-            for (int pj = 0; pj < NPJ; ++pj)
-#pragma unroll
-                for (int ej = 0; ej < 2; ++ej)
-                    t.f[2 * pi + ei][2 * pj + ej] = mfma64(r.a[pi][ei], r.b[pj][ej], t.f[2 * pi + ei][2 * pj + ej]);
-}
 
 // t[I][J] += sum_{k < K} MI[I, k] * MJ[J, k]   (opI = &MI[I0, 0], opJ = &MJ[J0, 0]; both column-major
 // with the tile index along the contiguous dimension).  The two operands are prefetched into separate
@@ -71,11 +49,11 @@ __device__ __forceinline__ void mfma_step(WaveTile<NPI, NPJ> &t, const OperandRe
 // (depth PFI k-steps), the J operand is this wave's own stream from HBM and needs the deeper ring (PFJ,
 // a multiple of PFI).  K must be a positive multiple of 4*PFJ.
 template <int NPI, int NPJ, int PFI, int PFJ = PFI>
-__device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const double *opI, int64_t ldI,
-                                        const double *opJ, int64_t ldJ, int K, int lane)
+__device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI,
+                                        const real *opJ, int64_t ldJ, int K, int lane)
 {
     static_assert(PFJ % PFI == 0, "the J ring depth must be a multiple of the I ring depth");
-    double2_t ra[PFI][NPI], rb[PFJ][NPJ];
+    real2_t ra[PFI][NPI], rb[PFJ][NPJ];
 #pragma unroll
     for (int s = 0; s < PFI; ++s)
 #pragma unroll
@@ -97,7 +75,7 @@ __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const double *opI
 #pragma unroll
                         for (int ej = 0; ej < 2; ++ej)
                             t.f[2 * pi + ei][2 * pj + ej] =
-                                mfma64(ra[si][pi][ei], rb[s][pj][ej], t.f[2 * pi + ei][2 * pj + ej]);
+                                mfma_real(ra[si][pi][ei], rb[s][pj][ej], t.f[2 * pi + ei][2 * pj + ej]);
             // refill both slots behind their own MFMAs; the tail re-reads the last k-step instead of branching
             int ki = k0 + 4 * (s + PFI), kj = k0 + 4 * (s + PFJ);
             ki = ki < K ? ki : K - 4;
@@ -128,62 +106,62 @@ constexpr int TRI_LDS_DOUBLES = 10 * 32 * 32;
 
 // cooperative copy by all `nthreads` threads of the workgroup; caller synchronises before and after.
 // L: factored diagonal tile (column-major, ldl); ninv: its 4 negated inverted diagonal blocks (global)
-__device__ __forceinline__ void stage_tri_operands(double *lds, const double *L, int64_t ldl, const double *ninv,
+__device__ __forceinline__ void stage_tri_operands(real *lds, const real *L, int64_t ldl, const real *ninv,
                                                    int tid, int nthreads)
 {
     // 16-byte pieces: 512 per block
     for (int e = tid; e < 10 * 512; e += nthreads) {
         const int b = e >> 9, w = e & 511;          // block, piece
         const int i = 2 * (w & 15), c = w >> 4;     // rows i, i+1 of column c
-        double2_t v;
+        real2_t v;
         if (b < 6) {
             const int s = (b >= 3) ? 3 : (b >= 1 ? 2 : 1);
             const int j = b - s * (s - 1) / 2;
-            v = *reinterpret_cast<const double2_t *>(L + 32 * s + i + (int64_t)(32 * j + c) * ldl);
+            v = *reinterpret_cast<const real2_t *>(L + 32 * s + i + (int64_t)(32 * j + c) * ldl);
         } else {
-            v = *reinterpret_cast<const double2_t *>(ninv + 1024 * (b - 6) + i + 32 * c);
+            v = *reinterpret_cast<const real2_t *>(ninv + 1024 * (b - 6) + i + 32 * c);
         }
-        *reinterpret_cast<double2_t *>(lds + 1024 * b + i + 32 * c) = v;
+        *reinterpret_cast<real2_t *>(lds + 1024 * b + i + 32 * c) = v;
     }
 }
 
 template <int NPJ>
-__device__ __forceinline__ void tri_solve_inplace(WaveTile<4, NPJ> &t, const double *lds, int lane)
+__device__ __forceinline__ void tri_solve_inplace(WaveTile<4, NPJ> &t, const real *lds, int lane)
 {
-    const double *base = lds + 2 * (lane & 15) + 32 * (2 * (lane >> 4));
+    const real *base = lds + 2 * (lane & 15);     // + 32 * (k index): k = 2 frag_irow(lane >> 4, q) + e
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int pj = 0; pj < s; ++pj) {
-            const double *blk = base + 1024 * (s * (s - 1) / 2 + pj);
+            const real *blk = base + 1024 * (s * (s - 1) / 2 + pj);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const double2_t a = *reinterpret_cast<const double2_t *>(blk + 32 * (8 * q + e));
+                    const real2_t a = *reinterpret_cast<const real2_t *>(blk + 32 * (2 * frag_irow(lane >> 4, q) + e));
 #pragma unroll
                     for (int j = 0; j < 2 * NPJ; ++j) {
-                        t.f[2 * s + 0][j] = mfma64(a[0], t.f[2 * pj + e][j][q], t.f[2 * s + 0][j]);
-                        t.f[2 * s + 1][j] = mfma64(a[1], t.f[2 * pj + e][j][q], t.f[2 * s + 1][j]);
+                        t.f[2 * s + 0][j] = mfma_real(a[0], t.f[2 * pj + e][j][q], t.f[2 * s + 0][j]);
+                        t.f[2 * s + 1][j] = mfma_real(a[1], t.f[2 * pj + e][j][q], t.f[2 * s + 1][j]);
                     }
                 }
             }
         }
-        double4_t o[2][2 * NPJ];
+        real4_t o[2][2 * NPJ];
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int j = 0; j < 2 * NPJ; ++j) o[e][j] = double4_t{0.0, 0.0, 0.0, 0.0};
-        const double *blk = base + 1024 * (6 + s);
+            for (int j = 0; j < 2 * NPJ; ++j) o[e][j] = real4_t{0, 0, 0, 0};
+        const real *blk = base + 1024 * (6 + s);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const double2_t a = *reinterpret_cast<const double2_t *>(blk + 32 * (8 * q + e));
+                const real2_t a = *reinterpret_cast<const real2_t *>(blk + 32 * (2 * frag_irow(lane >> 4, q) + e));
 #pragma unroll
                 for (int j = 0; j < 2 * NPJ; ++j) {
-                    o[0][j] = mfma64(a[0], t.f[2 * s + e][j][q], o[0][j]);
-                    o[1][j] = mfma64(a[1], t.f[2 * s + e][j][q], o[1][j]);
+                    o[0][j] = mfma_real(a[0], t.f[2 * s + e][j][q], o[0][j]);
+                    o[1][j] = mfma_real(a[1], t.f[2 * s + e][j][q], o[1][j]);
                 }
             }
         }
@@ -195,4 +173,5 @@ __device__ __forceinline__ void tri_solve_inplace(WaveTile<4, NPJ> &t, const dou
     }
 }
 
+}  // namespace PMK_NS
 }  // namespace pmk

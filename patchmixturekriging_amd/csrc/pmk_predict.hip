@@ -16,6 +16,7 @@
 #include "pmk_mfma.h"
 
 namespace pmk {
+namespace PMK_NS {
 
 constexpr int PF_PRED = 4;
 #ifndef PMK_PFJ
@@ -31,18 +32,18 @@ struct StripTask {
 
 template <int D, int FAM>
 __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *__restrict__ descs,
-                                                               const double *__restrict__ x, const double *__restrict__ A,
-                                                               const double *__restrict__ inv, const double *__restrict__ cvec,
+                                                               const real *__restrict__ x, const real *__restrict__ A,
+                                                               const real *__restrict__ inv, const real *__restrict__ cvec,
                                                                const StripTask *__restrict__ tasks, int ntasks,
                                                                const int32_t *__restrict__ sorted_item,
                                                                const int32_t *__restrict__ item_query,
-                                                               const double *__restrict__ xq, double *__restrict__ strips,
+                                                               const double *__restrict__ xq, real *__restrict__ strips,
                                                                int64_t strip_stride, pmk_kernel_desc th,
                                                                double *__restrict__ u_out, double *__restrict__ v_out)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *V = strips + (int64_t)blockIdx.x * strip_stride + 32 * wave;   // this wave's 32 columns, ld = TQ
-    __shared__ double tri[TRI_LDS_DOUBLES];     // TRSM operands of the current block row (shared by the 4 waves)
+    real *V = strips + (int64_t)blockIdx.x * strip_stride + 32 * wave;   // this wave's 32 columns, ld = TQ
+    __shared__ real tri[TRI_LDS_DOUBLES];     // TRSM operands of the current block row (shared by the 4 waves)
 
     // XCD-aware task order: the workgroups of one XCD take consecutive tasks (= strips of the same
     // region, which stream the same factor L) so that L is fetched into one L2 once per region
@@ -55,13 +56,13 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
         const StripTask tk = tasks[task];
         const bool active = 32 * wave < tk.count;     // wave-uniform; idle waves still help stage operands
         const PatchDesc pd = descs[tk.region];
-        const double *S = A + pd.aoff;
-        const double *xs = x + pd.xoff;
-        const double *cr = cvec + pd.yoff;
+        const real *S = A + pd.aoff;
+        const real *xs = x + pd.xoff;
+        const real *cr = cvec + pd.yoff;
         const int64_t ld = pd.ld;
 
         // the lane's 2 query columns: 2 (lane & 15) + ej of the wave's 32
-        double q[2][D];
+        real q[2][D];
         int64_t pos[2];
         bool valid[2];
 #pragma unroll
@@ -71,9 +72,9 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
             pos[ej] = tk.first + (valid[ej] ? col : 0);                // padding columns repeat a valid item
             const int64_t qi = item_query[sorted_item[pos[ej]]];
 #pragma unroll
-            for (int d = 0; d < D; ++d) q[ej][d] = xq[qi * D + d];
+            for (int d = 0; d < D; ++d) q[ej][d] = (real)xq[qi * D + d];
         }
-        double mu[2] = {0.0, 0.0}, vs[2] = {0.0, 0.0};
+        real mu[2] = {0.0, 0.0}, vs[2] = {0.0, 0.0};
 
         for (int i = 0; i < pd.nt; ++i) {
             __syncthreads();                          // every wave is done with the previous block row's operands
@@ -87,17 +88,17 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
             for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
-                    const int row = i * TILE + 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * qq) + (fi & 1);
-                    double xr[D];
+                    const int row = i * TILE + tile_i(fi, lane, qq);
+                    real xr[D];
 #pragma unroll
                     for (int d = 0; d < D; ++d) xr[d] = xs[(int64_t)d * ld + row];
-                    const double cw = cr[row];
+                    const real cw = cr[row];
                     // padding rows carry coordinates of 1e300 (pack_soa): a compactly supported profile is
                     // exactly 0 there, so the Spline34 instantiation needs no bounds test in its unrolled tile
                     const bool inside = (FAM == PMK_SPLINE34) || row < pd.n;
 #pragma unroll
                     for (int ej = 0; ej < 2; ++ej) {
-                        const double kv = inside ? kern_eval<D, FAM>(th, q[ej], xr) : 0.0;
+                        const real kv = inside ? kern_eval<D, FAM, real>(th, q[ej], xr) : 0.0;
                         acc.f[fi][ej][qq] = kv;
                         mu[ej] += kv * cw;
                     }
@@ -121,25 +122,25 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
                 for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
-                        const int row = i * TILE + 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * qq) + (fi & 1);
-                        double2_t o;
+                        const int row = i * TILE + tile_i(fi, lane, qq);
+                        real2_t o;
                         o[0] = acc.f[fi][0][qq];
                         o[1] = acc.f[fi][1][qq];
-                        *reinterpret_cast<double2_t *>(V + (int64_t)row * TQ + 2 * (lane & 15)) = o;
+                        *reinterpret_cast<real2_t *>(V + (int64_t)row * TQ + 2 * (lane & 15)) = o;
                     }
             }
         }
         // ---- reduce over the four lane groups that share a column, then write (u, v)
 #pragma unroll
         for (int ej = 0; ej < 2 && active; ++ej) {
-            double a = mu[ej], b = vs[ej];
+            real a = mu[ej], b = vs[ej];
             a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
             a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
             if ((lane >> 4) == 0 && valid[ej]) {
-                const double kself = kern_eval<D, FAM>(th, q[ej], q[ej]);
-                double var = kself - b;                               // mixtureGP.jl:312
+                const real kself = kern_eval<D, FAM, real>(th, q[ej], q[ej]);
+                double var = (double)kself - (double)b;               // mixtureGP.jl:312
                 var = var < 1e-12 ? 1e-12 : var;
-                u_out[pos[ej]] = a;
+                u_out[pos[ej]] = (double)a;
                 v_out[pos[ej]] = var;
             }
         }
@@ -177,7 +178,7 @@ int build_strip_tasks(pmk_query *q, hipStream_t s)
         if (m->d_strip) PMK_HIP(hipFree(m->d_strip));
         m->d_strip = nullptr;
         m->strip_slots = 0;
-        PMK_HIP(hipMalloc((void **)&m->d_strip, sizeof(double) * stride * slots));
+        PMK_HIP(hipMalloc(&m->d_strip, sizeof(real) * stride * slots));
         m->strip_slots = slots;
     }
     q->strip_grid = slots;
@@ -196,12 +197,12 @@ int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s)
     case DD:                                                                                                           \
         if (s34)                                                                                                       \
             hipLaunchKernelGGL((predict_strip_kernel<DD, PMK_SPLINE34>), dim3((unsigned)q->strip_grid), dim3(256), 0, s, \
-                               m->d_desc, m->d_x, m->d_a, m->d_inv, m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
-                               q->d_item_query, q->d_xq, m->d_strip, stride, th, q->d_u, q->d_v);                       \
+                               m->d_desc, (real *)m->d_x, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
+                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_u, q->d_v);                       \
         else                                                                                                           \
             hipLaunchKernelGGL((predict_strip_kernel<DD, 0>), dim3((unsigned)q->strip_grid), dim3(256), 0, s,           \
-                               m->d_desc, m->d_x, m->d_a, m->d_inv, m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
-                               q->d_item_query, q->d_xq, m->d_strip, stride, th, q->d_u, q->d_v);                       \
+                               m->d_desc, (real *)m->d_x, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
+                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_u, q->d_v);                       \
         break;
         PMK_CASE(1) PMK_CASE(2) PMK_CASE(3) PMK_CASE(4)
 #undef PMK_CASE
@@ -213,4 +214,5 @@ int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s)
     return 0;
 }
 
+}  // namespace PMK_NS
 }  // namespace pmk

@@ -6,6 +6,7 @@
 #include "pmk_mfma.h"
 
 namespace pmk {
+using namespace f64;
 
 __global__ __launch_bounds__(64) void selftest_gemm_kernel(int K, const double *MI, const double *MJ, double *C)
 {
@@ -58,9 +59,9 @@ __global__ __launch_bounds__(64) void selftest_trisolve_kernel(const double *L, 
 // 16 independent accumulators per wave, operands in registers, no memory traffic in the loop
 __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double *sink)
 {
-    double4_t acc[16];
+    real4_t acc[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < 16; ++i) acc[i] = real4_t{0.0, 0.0, 0.0, 0.0};
     double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll

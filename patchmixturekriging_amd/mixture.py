@@ -39,7 +39,7 @@ class PosDefException(np.linalg.LinAlgError):
 class DeviceModel:
     """pmk_model: the fitted per-patch factors, resident on the GPU"""
 
-    def __init__(self, X_parts, y_parts, ctx=None, _factors=None):
+    def __init__(self, X_parts, y_parts, ctx=None, _factors=None, dtype="f64"):
         self.ctx = ctx or default_context()
         L = self.ctx.L
         self.X = [as_points(x) for x in X_parts]
@@ -54,9 +54,12 @@ class DeviceModel:
                 raise ValueError("length(c) == length(X) must hold per patch")     # mixtureGP.jl:298
         PA = _dp * self.P
         h = C.c_void_p()
+        self.dtype = dtype
         if _factors is None:
-            _lib.check(L.pmk_model_create(self.ctx.h, self.D, self.P, _i(self.n), PA(*[_d(x) for x in self.X]),
-                                          PA(*[_d(y) for y in ys]), C.byref(h)), "pmk_model_create")
+            # dtype "f32": fp32 storage + fp32 MFMA on the device (BASELINE config E); host buffers stay float64
+            _lib.check(L.pmk_model_create_ex(self.ctx.h, self.D, self.P, _i(self.n), PA(*[_d(x) for x in self.X]),
+                                             PA(*[_d(y) for y in ys]), {"f64": 0, "f32": 1}[dtype], C.byref(h)),
+                       "pmk_model_create")
         else:
             Ls = [np.asfortranarray(l, dtype=np.float64) for l in _factors]
             ldl = np.array([l.shape[0] for l in Ls], dtype=np.int64)
@@ -183,9 +186,9 @@ class DeviceQuery:
                     item_v=v[:n])
 
 
-def fit_patches(X_parts, y_parts, theta, sigma2, ctx=None):
+def fit_patches(X_parts, y_parts, theta, sigma2, ctx=None, dtype="f64"):
     """create + fit + info + weights: the batched path behind fitmixtureGP! and fitRKHS!"""
-    model = DeviceModel(X_parts, y_parts, ctx)
+    model = DeviceModel(X_parts, y_parts, ctx, dtype=dtype)
     model.fit(theta, sigma2)
     info = model.info()
     cs = [model.get(r, GET_C) for r in range(model.P)]

@@ -560,3 +560,43 @@ def test_config_E_shape_in_fp64_properties():
         s = slice(dbg["item_offsets"][j], dbg["item_offsets"][j + 1])
         mu, var = O.queryinner(oth, Xr, c, L, Xq[j])
         assert abs(dbg["item_u"][s][-1] - mu) <= 1e-9 * max(1, abs(mu)) and abs(dbg["item_v"][s][-1] - var) <= 1e-9 + 1e-5 * var
+
+
+# ------------------------------------------------------------------------------------ fp32 path (config E arithmetic)
+def test_fp32_path_against_fp64_oracle():
+    """fp32 storage + v_mfma_f32 (dtype "f32").  The reference is Float64-only, so this path is judged against
+    the fp64 oracle with eps32-scaled bounds: a compact kernel / noise pair with cond(U) ~ 1e3 keeps
+    cond * eps32 << 1 (the wide example kernel is not positive definite in fp32)."""
+    X, y, Xq = _mixgp_case(3000, 4, 0.3, 1.0, 1e-2, 0.3, 1e-5, 1500, 13)
+    levels, eps, a, sigma2, radius, delta = 4, 0.3, 1.0, 1e-2, 0.3, 1e-5
+    y = np.sin(X[:, 0]) * np.cos(0.5 * X[:, 1])
+    th, wth = pmk.Spline34KernelType(a), pmk.Spline34KernelType(1 / radius)
+    oth, owth = O.kernel(O.SPLINE34, a), O.kernel(O.SPLINE34, 1 / radius)
+    root, _, _ = pmk.setuppartition(X, levels)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, X, eps)
+    ys = [y[i] for i in X_set_inds]
+    m32 = pmk.DeviceModel(X_set, ys, dtype="f32")
+    m32.fit(th, sigma2)
+    assert np.all(m32.info() == 0)
+    fits = [O.fit_patch(oth, xs, yy, sigma2, want_K=True) for xs, yy in zip(X_set, ys)]
+    for r in (0, len(X_set) - 1):
+        L, c = m32.get(r, M.GET_L), m32.get(r, M.GET_C)
+        U = fits[r]["K"] + sigma2 * np.eye(len(ys[r]))
+        assert np.abs(L - fits[r]["L"]).max() < 2e-4                       # ~ cond * eps32
+        assert np.linalg.norm(L @ L.T - U) / np.linalg.norm(U) < 1e-5
+        assert np.linalg.norm(U @ c - ys[r]) / (np.linalg.norm(U) * np.linalg.norm(c) + np.linalg.norm(ys[r])) < 1e-5
+    m32.set_bsp(root, 0)
+    q = pmk.DeviceQuery(m32, Xq)
+    q.plan(radius, delta); q.items(th); q.mix(wth)
+    Yq, Vq = q.fetch()
+    dbg = q.debug()
+    ob = O.BSP(X, levels)
+    oY, oV, ohome, ooff, oreg, ots = O.query_mixture(ob, oth, owth, X_set, [f["c_lu"] for f in fits], [f["L"] for f in fits],
+                                                     Xq, radius, delta, debug=True, nthreads=8)
+    assert np.array_equal(dbg["home"], ohome) and np.array_equal(dbg["item_offsets"][1:] - dbg["item_offsets"][:-1] - 1, np.diff(ooff))
+    assert np.abs(Yq - oY).max() < 2e-3 and np.all(np.abs(Vq - oV) < 2e-3 + 1e-2 * oV)
+    # the fp64 model on the same data is tighter by orders of magnitude (sanity of the comparison itself)
+    m64 = pmk.DeviceModel(X_set, ys); m64.fit(th, sigma2); m64.set_bsp(root, 0)
+    q64 = pmk.DeviceQuery(m64, Xq); q64.plan(radius, delta); q64.items(th); q64.mix(wth)
+    Y64, V64 = q64.fetch()
+    assert np.abs(Y64 - oY).max() < 1e-9 and np.abs(Yq - Y64).max() > 1e-9
