@@ -43,11 +43,34 @@ __device__ __forceinline__ double pow4_cr(double t)
     const dd_t t4 = dd_sqr(dd_sqr(dd_t{t, 0.0}));
     return t4.hi + t4.lo;
 }
+// t^6 = (t^3)^2 with t^3 carried as an unevaluated sum t3 + e3 (error-free products on FMA): 11 operations,
+// result within the rounding of the true power in all but vanishingly rare cases.
 __device__ __forceinline__ double pow6_cr(double t)
 {
-    const dd_t t2 = dd_sqr(dd_t{t, 0.0});
-    const dd_t t6 = dd_mul(dd_sqr(t2), t2);
-    return t6.hi + t6.lo;
+    const double t2 = t * t;
+    const double e2 = __builtin_fma(t, t, -t2);
+    const double t3 = t2 * t;
+    const double e3 = __builtin_fma(e2, t, __builtin_fma(t2, t, -t3));
+    const double t6 = t3 * t3;
+    const double e6 = __builtin_fma(2.0 * t3, e3, __builtin_fma(t3, t3, -t6));
+    return t6 + e6;
+}
+
+// sqrt for the distance of two points: x >= 0 and far from the subnormal / overflow ranges, so the range
+// scaling of the library sqrt is dropped: v_rsq_f64 seed, one Goldschmidt step, two FMA corrections (the
+// library's own tail) -> correctly rounded; 0 maps to 0 through the select.
+__device__ __forceinline__ double sqrt_dist(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x == 0.0 || x > 1e300) ? x : g;
 }
 
 // x / 3.0, correctly rounded, without the ~30-instruction IEEE division sequence: q = RN(x * RN(1/3)),
@@ -186,7 +209,8 @@ __device__ __forceinline__ R kern_eval(const pmk_kernel_desc &th, const R *p, co
         R r = p[d] - q[d];
         s = s + r * r;
     }
-    return profile<FAM, R>(th, sqrt(s));
+    if constexpr (sizeof(R) == 8) return profile<FAM, R>(th, sqrt_dist(s));
+    else return profile<FAM, R>(th, sqrt(s));
 }
 
 // dot(u, x) as the reference's short ddot: sequential multiply-add, no FMA
