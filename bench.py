@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--patches", type=int, default=256, help="patches per GPU")
     ap.add_argument("--n", type=int, default=2000, help="points per patch")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--eps", type=float, default=0.0,
+                    help="overlap of the training sets (organizetrainingsets); 0.044 gives the ragged 'realistic' "
+                         "variant of config C (n ~ 1.8k-2.2k per patch, SURVEY 8(d))")
     ap.add_argument("--config", default="C", choices=["C", "E"],
                     help="C: headline 2-D fp64 256 x 2000 (default).  E: 3-D, 128 x 8192, fp32 (BASELINE config E; "
                          "not the headline: no CPU leg, fp32 MFMA peak)")
@@ -118,6 +121,8 @@ def main():
     t0 = time.time()
     root, X_parts, X_parts_inds = pmk.setuppartition(X, levels)        # host, exact; replicated on every rank
     t_bsp = time.time() - t0
+    if args.eps > 0:      # overlapping training sets: ragged patch sizes
+        X_parts, X_parts_inds, _, _ = pmk.organizetrainingsets(root, levels, X, args.eps)
     sizes = [len(p) for p in X_parts]
     # radius = 0.1 x patch width: patch area = 200 / (P world)
     radius = 0.1 * (1.0 / (P * world)) ** (1 / 3) if cfgE else 0.1 * np.sqrt(200.0 / (P * world))
@@ -204,17 +209,18 @@ def main():
         return
 
     # ---------------------------------------------------------------- roofline of the dominant kernel
-    ld = ((n + 127) // 128) * 128
+    nmax = max(sizes)
+    ld = ((nmax + 127) // 128) * 128
     nt = ld // 128
     roof = None
     if "panel" in stage:
-        flops = P * panel_flops(ld)
+        flops = sum(panel_flops(((s + 127) // 128) * 128) for s in sizes[lo:hi])
         roof = {"bound": "mfma", "kernel": "chol_panel_kernel", "achieved": flops / (stage["panel"] * 1e-3) / 1e12,
                 "peak": FP32_PEAK_TFLOPS if cfgE else FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
                 "launches_per_step": nt - 1, "avg_launch_ms": stage["panel"] / (nt - 1),
                 "alg_flops_per_launch": flops / (nt - 1)}
     elif "cholesky" in stage:
-        flops = P * chol_flops(n)
+        flops = sum(chol_flops(s) for s in sizes[lo:hi])
         roof = {"bound": "mfma", "kernel": "chol_diag_kernel+chol_panel_kernel", "achieved": flops / (stage["cholesky"] * 1e-3) / 1e12,
                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
     if roof:
@@ -223,7 +229,7 @@ def main():
         # correction + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command; see the file's note)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if "panel" in roof["kernel"] and (P, n) == (256, 2000):
+            if "panel" in roof["kernel"] and (P, n) == (256, 2000) and args.eps == 0:
                 roof["traffic"] = pmc["chol_panel_kernel"]["hbm_bytes_per_launch"]
                 roof["traffic_source"] = "profiles/r01_pmc_traffic.json"
         except Exception:

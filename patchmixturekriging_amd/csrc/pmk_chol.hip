@@ -4,10 +4,12 @@
 //
 // Step k of the factorisation (k = 0 .. nt-1), all patches at once, two launches:
 //   chol_diag_kernel  : one workgroup per patch.  Applies the last block column to the diagonal tile
-//                       (T = A[kk] - L[k,k-1] L[k,k-1]^T, MFMA), factors T in LDS with a 32-wide blocked
-//                       potrf, stores L[kk] and the negated inverses of its four 32 x 32 diagonal
-//                       blocks (every later TRSM is MFMA block substitution with them), and advances the
-//                       forward solve: z_k = L[kk]^-1 (y_k - L[k,0:k] z_0:k).
+//                       (A[kk] -= L[k,k-1] L[k,k-1]^T, MFMA, in place in the slab), factors it with the tile
+//                       distributed over the registers of the 256 threads (right-looking, two barriers per
+//                       pivot), stores L[kk] and the negated inverses of its four 32 x 32 diagonal blocks
+//                       (every later TRSM is MFMA block substitution with them); the right-hand side rides
+//                       along as an extra row, so z_k = L[kk]^-1 (y_k - L[k,0:k] z_0:k) falls out of the
+//                       same elimination.
 //   chol_panel_kernel : grid over the block rows below + one "look-ahead" workgroup per patch.
 //                       Block rows: T = A[i,k] - L[i,0:k] L[k,0:k]^T on MFMA (the contraction the north
 //                       star prices), then L[i,k] = T L[kk]^-T by in-register block substitution.
@@ -23,7 +25,6 @@
 namespace pmk {
 namespace PMK_NS {
 
-constexpr int LDT = TILE + 1;   // LDS leading dimension of the diagonal tile (row access conflict-free)
 constexpr int PF_CHOL = 4;      // I-operand prefetch depth (k-steps) of the panel GEMM; must divide TILE/4
 #ifndef PMK_PFJ
 #define PMK_PFJ 4
@@ -31,10 +32,6 @@ constexpr int PF_CHOL = 4;      // I-operand prefetch depth (k-steps) of the pan
 constexpr int PFJ_CHOL = PMK_PFJ;   // J-operand (own rows, HBM) prefetch depth
 constexpr int PF_DIAG = 4;
 constexpr int SB = 32;          // sub-block of the in-LDS potrf and of the TRSM block substitution
-
-// element (i, c) of the negated inverse of diagonal sub-block s is parked in the unused upper-right
-// quadrant of the LDS tile: rows [32 (s&1), +32) x columns [64 + 32 (s>>1), +32)
-__device__ __forceinline__ int ninv_lds(int s, int i, int c) { return (32 * (s & 1) + i) + (64 + 32 * (s >> 1) + c) * LDT; }
 
 // Fused kernel-matrix build (K1 folded into the factorisation): entry (i, j) of U = K + sigma2 I of a
 // patch, evaluated from the resident coordinates exactly as constructkernelmatrix! + the diagonal update
@@ -65,17 +62,21 @@ struct TileSource {
 // diagonal block
 // ---------------------------------------------------------------------------------------------
 template <int D, int FAM, int FUSE>
-__global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restrict__ descs, real *__restrict__ A,
-                                                        real *__restrict__ ninv, const real *__restrict__ y,
-                                                        const real *__restrict__ ytmp, real *__restrict__ z,
-                                                        int32_t *__restrict__ info, int k,
-                                                        const real *__restrict__ x, pmk_kernel_desc th, double sigma2,
-                                                        int skip)
+__global__ __launch_bounds__(256, 2) void chol_diag_kernel(const PatchDesc *__restrict__ descs, real *__restrict__ A,
+                                                           real *__restrict__ ninv, const real *__restrict__ y,
+                                                           const real *__restrict__ ytmp, real *__restrict__ z,
+                                                           int32_t *__restrict__ info, int k,
+                                                           const real *__restrict__ x, pmk_kernel_desc th, double sigma2,
+                                                           int skip)
 {
     const PatchDesc pd = descs[blockIdx.x];
     if (k >= pd.nt) return;
-    __shared__ real T[TILE * LDT];
+    // LDS stays small (~38 KB, 256 registers): the tile itself lives in the slab (L2) and in registers, so a
+    // diagonal workgroup can share a CU with a panel workgroup of another sub-batch (PMK_FIT_GROUPS)
+    __shared__ real dblk[4][SB][SB + 1];     // the four 32 x 32 diagonal blocks of L[kk], for their inversion
+    __shared__ real col[TILE + 1];           // scaled pivot column; col[TILE] = the forward-solve entry z_j
     __shared__ real rhs[2 * TILE];
+    __shared__ real sdiag;
     __shared__ int s_bad;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,12 +87,12 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
     real *Akk = S + d0 + d0 * ld;
     if (tid == 0) s_bad = 0;
 
-    // ---- T = A[kk] - L[k,k-1] L[k,k-1]^T   (older block columns were applied by the look-ahead
+    // ---- A[kk] -= L[k,k-1] L[k,k-1]^T in place in the slab (older block columns were applied by the look-ahead
     //      workgroup of the previous panel launch); lower 64 x 64 sub-tiles only
-    if (!(h == 0 && g == 1)) {
+    if (!(h == 0 && g == 1) && ((k > 0 && !(skip & 16)) || (FUSE && k == 0))) {
         WaveTile<2, 2> acc;
         acc.zero();
-        if (k > 0 && !(skip & 16)) {
+        if (k > 0) {
             const real *Lk = S + d0 + (d0 - TILE) * ld;      // L[k, k-1]: 128 x 128
             gemm_nt<2, 2, PF_DIAG>(acc, Lk + 64 * g, ld, Lk + 64 * h, ld, TILE, lane);
         }
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
                 for (int pj = 0; pj < 2; ++pj) {
                     const int cl = 64 * g + tile_i(fi, lane, q);
                     const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
+                    real2_t *p = reinterpret_cast<real2_t *>(Akk + rl + (int64_t)cl * ld);
                     real2_t a;
                     if (FUSE && k == 0) {          // first tile: nothing was written to the slab, evaluate K here
                         const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
@@ -111,10 +113,11 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
                         a[0] = src.value(rl, pr0, cl, pc);
                         a[1] = src.value(rl + 1, pr1, cl, pc);
                     } else {
-                        a = *reinterpret_cast<const real2_t *>(Akk + rl + (int64_t)cl * ld);
+                        a = *p;
                     }
-                    T[rl + cl * LDT] = a[0] - acc.f[fi][2 * pj][q];
-                    T[rl + 1 + cl * LDT] = a[1] - acc.f[fi][2 * pj + 1][q];
+                    a[0] -= acc.f[fi][2 * pj][q];
+                    a[1] -= acc.f[fi][2 * pj + 1][q];
+                    *p = a;
                 }
     }
     // ---- forward-solve right-hand side: y_k - L[k,0:k-1] z (look-ahead) - L[k,k-1] z_{k-1}
@@ -128,37 +131,39 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
         }
         rhs[tid] = s;
     }
+    __threadfence_block();
     __syncthreads();
     if (tid < TILE) {
         const real base = (k == 0) ? y[pd.yoff + tid] : ytmp[pd.yoff + d0 + tid];
         rhs[tid] = base - (rhs[tid] + rhs[tid + TILE]);
     }
-
-    // ---- potrf of T: right-looking, the tile distributed over the registers of all 256 threads
-    //      (thread (tr, tc) of a 16 x 16 grid holds A[tr + 16 a][tc + 16 b], a, b < 8).  Per pivot: the 16
-    //      threads that own column j scale it and publish it through LDS, one barrier, every thread applies
-    //      the rank-1 update to its own entries, one barrier.  The pivot's reciprocal square root comes from
-    //      v_rsq_f64 + two Newton steps (a dependent chain of ~10 FMAs instead of the IEEE sqrt + divide
-    //      sequences: the 128 pivots are a serial latency chain, this is its critical path).
     __syncthreads();
+
+    // ---- potrf of the tile: right-looking, the tile distributed over the registers of all 256 threads
+    //      (thread (tr, tc) of a 16 x 16 grid holds A[tr + 16 a][tc + 16 b], a, b < 8; the threads with tr == 0
+    //      also carry the right-hand side as an extra row, which the elimination turns into z_k = L[kk]^-1 rhs).
+    //      Per pivot: the 16 threads that own column j scale it and publish it through LDS, one barrier, every
+    //      thread applies the rank-1 update to its own entries, one barrier.  The pivot's reciprocal square root
+    //      comes from v_rsq + Newton steps: the 128 pivots are a serial latency chain, this is its critical path.
     {
-        __shared__ real col[TILE];
-        __shared__ real sdiag;
         const int tr = tid & 15, tc = tid >> 4;
-        real a_[8][8];
+        real a_[8][8], rr[8];
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
-            for (int b2 = 0; b2 < 8; ++b2) a_[a][b2] = (b2 <= a) ? T[(tr + 16 * a) + (tc + 16 * b2) * LDT] : 0.0;
-        if (tid == 0) sdiag = T[0];
+            for (int b2 = 0; b2 < 8; ++b2)
+                a_[a][b2] = (b2 <= a) ? Akk[(tr + 16 * a) + (int64_t)(tc + 16 * b2) * ld] : (real)0;
+#pragma unroll
+        for (int b2 = 0; b2 < 8; ++b2) rr[b2] = rhs[tc + 16 * b2];
+        if (tid == 0) sdiag = a_[0][0];
         __syncthreads();
         for (int j = 0; j < ((skip & 1) ? 0 : TILE); ++j) {
             const int bj = j >> 4;
             if (tc == (j & 15)) {
                 real d = sdiag;
-                if (!(d > 0.0)) {                         // not positive definite (or NaN): record, keep going
+                if (!(d > (real)0)) {                     // not positive definite (or NaN): record, keep going
                     if (tr == 0 && s_bad == 0) s_bad = k * TILE + j + 1;
-                    d = 1.0;
+                    d = 1;
                 }
                 const real rs = rsqrt_real(d);
                 const real ljj = d * rs;
@@ -170,7 +175,11 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
                             const int r = tr + 16 * a;
                             const real v = (r > j) ? a_[a][b2] * rs : ((r == j) ? ljj : a_[a][b2]);
                             a_[a][b2] = v;
-                            col[r] = (r > j) ? v : 0.0;
+                            col[r] = (r > j) ? v : (real)0;
+                        }
+                        if (tr == 0) {                    // the extra row: z_j = rhs_j / L[j][j]
+                            rr[b2] = rr[b2] * rs;
+                            col[TILE] = rr[b2];
                         }
                     }
             }
@@ -185,6 +194,11 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
                     for (int b2 = 0; b2 <= a; ++b2)
                         if (16 * b2 + 15 > j) a_[a][b2] -= cr[a] * cc[b2];
                 }
+            if (tr == 0) {
+                const real zj = col[TILE];
+#pragma unroll
+                for (int b2 = 0; b2 < 8; ++b2) rr[b2] -= zj * cc[b2];       // cc is 0 for columns <= j
+            }
             // publish the next pivot's diagonal entry
             if (j + 1 < TILE && tr == ((j + 1) & 15) && tc == ((j + 1) & 15)) {
                 const int bn = (j + 1) >> 4;
@@ -194,59 +208,39 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const PatchDesc *__restr
             }
             __syncthreads();
         }
+        // ---- L[kk] -> slab (lower; the strict upper part of the slab block is zeroed), the four diagonal
+        //      32 x 32 blocks -> LDS for their inversion, z_k -> global
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
-            for (int b2 = 0; b2 <= a; ++b2) {
+            for (int b2 = 0; b2 < 8; ++b2) {
                 const int r = tr + 16 * a, c = tc + 16 * b2;
-                if (r >= c) T[r + c * LDT] = a_[a][b2];
+                const real v = (b2 <= a && r >= c) ? a_[a][b2] : (real)0;
+                if (!(skip & 4)) Akk[r + (int64_t)c * ld] = v;
+                if ((r >> 5) == (c >> 5)) dblk[r >> 5][r & 31][c & 31] = v;
             }
-    }
-    __syncthreads();
-    // ---- negated inverses of the four 32 x 32 diagonal blocks: wave w inverts block w, one thread per column
-    if (lane < SB && !(skip & 2)) {
-        const int o = SB * wave, c = lane;
-        real x[SB];
+        if (tr == 0) {
 #pragma unroll
-        for (int i = 0; i < SB; ++i) {
-            real sacc = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int l = 0; l < i; ++l) sacc -= T[(o + i) + (o + l) * LDT] * x[l];
-            x[i] = sacc / T[(o + i) + (o + i) * LDT];
+            for (int b2 = 0; b2 < 8; ++b2) z[pd.yoff + d0 + tc + 16 * b2] = rr[b2];
         }
-#pragma unroll
-        for (int i = 0; i < SB; ++i) T[ninv_lds(wave, i, c)] = -x[i];
     }
     __syncthreads();
     if (tid == 0 && s_bad && info[blockIdx.x] == 0) info[blockIdx.x] = s_bad;
-
-    // ---- L[kk] -> slab (lower; the strict upper part of the slab block is zeroed); -D^-1 blocks -> global
-    for (int e = tid; e < ((skip & 4) ? 0 : TILE * TILE); e += 256) {
-        const int i = e & 127, c = e >> 7;
-        Akk[i + (int64_t)c * ld] = (i >= c) ? T[i + c * LDT] : 0.0;
-    }
-    real *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
-    for (int e = tid; e < 4 * SB * SB; e += 256) {
-        const int s = e >> 10, i = e & 31, c = (e >> 5) & 31;
-        Ni[e] = (i >= c) ? T[ninv_lds(s, i, c)] : 0.0;
-    }
-    // ---- z_k = L[kk]^-1 rhs by block forward substitution (threads 0..31 own one 32-row block at a time)
-    for (int s = 0; s < ((skip & 8) ? 0 : 4); ++s) {
-        if (tid < SB) {
-            const int r = SB * s + tid;
-            real v = rhs[r];
-            for (int c = 0; c < SB * s; ++c) v -= T[r + c * LDT] * rhs[TILE + c];
-            rhs[r] = v;
+    // ---- negated inverses of the four 32 x 32 diagonal blocks: wave w inverts block w, one thread per column
+    if (lane < SB && !(skip & 2)) {
+        const int c = lane;
+        real xcol[SB];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            real sacc = (i == c) ? (real)1 : (real)0;
+#pragma unroll
+            for (int l = 0; l < i; ++l) sacc -= dblk[wave][i][l] * xcol[l];
+            xcol[i] = sacc / dblk[wave][i][i];
         }
-        __syncthreads();
-        if (tid < SB) {
-            real v = 0.0;
-            for (int c = 0; c < SB; ++c) v -= T[ninv_lds(s, tid, c)] * rhs[SB * s + c];    // D^-1 r = -(Ninv r)
-            rhs[TILE + SB * s + tid] = v;
-        }
-        __syncthreads();
+        real *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB) + (int64_t)wave * (SB * SB);
+#pragma unroll
+        for (int i = 0; i < SB; ++i) Ni[i + SB * c] = (i >= c) ? -xcol[i] : (real)0;
     }
-    if (tid < TILE) z[pd.yoff + d0 + tid] = rhs[TILE + tid];
 }
 
 // ---------------------------------------------------------------------------------------------

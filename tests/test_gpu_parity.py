@@ -600,3 +600,26 @@ def test_fp32_path_against_fp64_oracle():
     q64 = pmk.DeviceQuery(m64, Xq); q64.plan(radius, delta); q64.items(th); q64.mix(wth)
     Y64, V64 = q64.fetch()
     assert np.abs(Y64 - oY).max() < 1e-9 and np.abs(Yq - Y64).max() > 1e-9
+
+
+def test_config_A_ibb1d_n512():
+    """BASELINE config A: IBB1D.jl scaled to N = 512, single patch, BrownianBridge10, sigma2 = 1e-5
+    (examples/IBB1D.jl:19-62) -- GPU path against the oracle's fitRKHS! / query!."""
+    N = 512
+    x = np.linspace(1e-5, 1 - 1e-5, N)                       # end points excluded (IBB1D.jl:28)
+    y = np.sinc(4 * x) * x ** 3
+    th, oth = pmk.BrownianBridge10(1.0), O.kernel(O.BB10, 1.0)
+    K = pmk.constructkernelmatrix(x[:, None], th)
+    assert np.array_equal(K, O.kernel_matrix(oth, x[:, None]))
+    assert np.linalg.matrix_rank(K) == N
+    eta = pmk.RKHSProblemType(np.zeros(N), x[:, None], th, 1e-5)
+    pmk.fitRKHS_(eta, y)
+    oc = O.fit_rkhs(oth, x[:, None], y, 1e-5)
+    U = K + 1e-5 * np.eye(N)
+    for c in (eta.c, oc):
+        assert np.linalg.norm(U @ c - y) / (np.linalg.norm(U) * np.linalg.norm(c) + np.linalg.norm(y)) < 1e-13
+    xq = np.linspace(0, 1, 100)
+    yq = np.empty(100)
+    pmk.query_(yq, xq[:, None], eta)
+    assert np.abs(yq - O.query_rkhs(oth, x[:, None], oc, xq[:, None])).max() < 1e-7
+    assert yq[0] == 0.0
