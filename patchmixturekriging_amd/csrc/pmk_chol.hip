@@ -157,56 +157,56 @@ __global__ __launch_bounds__(256, 2) void chol_diag_kernel(const PatchDesc *__re
         for (int b2 = 0; b2 < 8; ++b2) rr[b2] = rhs[tc + 16 * b2];
         if (tid == 0) sdiag = a_[0][0];
         __syncthreads();
-        for (int j = 0; j < ((skip & 1) ? 0 : TILE); ++j) {
-            const int bj = j >> 4;
-            if (tc == (j & 15)) {
-                real d = sdiag;
-                if (!(d > (real)0)) {                     // not positive definite (or NaN): record, keep going
-                    if (tr == 0 && s_bad == 0) s_bad = k * TILE + j + 1;
-                    d = 1;
-                }
-                const real rs = rsqrt_real(d);
-                const real ljj = d * rs;
+        // two-level pivot loop: the 16-column block index bj is a compile-time constant in each copy of the body, so
+        // a_[.][bj] is a static register reference and the update loops run over exactly the live blocks -- no
+        // per-pivot scalar branches (an earlier version guarded every 16 x 16 block with a runtime test: ~40
+        // s_cbranch per pivot cost more than the arithmetic they skipped)
 #pragma unroll
-                for (int b2 = 0; b2 < 8; ++b2)
-                    if (b2 == bj) {
-#pragma unroll
-                        for (int a = 0; a < 8; ++a) {
-                            const int r = tr + 16 * a;
-                            const real v = (r > j) ? a_[a][b2] * rs : ((r == j) ? ljj : a_[a][b2]);
-                            a_[a][b2] = v;
-                            col[r] = (r > j) ? v : (real)0;
-                        }
-                        if (tr == 0) {                    // the extra row: z_j = rhs_j / L[j][j]
-                            rr[b2] = rr[b2] * rs;
-                            col[TILE] = rr[b2];
-                        }
+        for (int bj = 0; bj < 8; ++bj) {
+            for (int jj = 0; jj < ((skip & 1) ? 0 : 16); ++jj) {
+                const int j = 16 * bj + jj;
+                if (tc == jj) {
+                    real d = sdiag;
+                    if (!(d > (real)0)) {                     // not positive definite (or NaN): record, keep going
+                        if (tr == 0 && s_bad == 0) s_bad = k * TILE + j + 1;
+                        d = 1;
                     }
-            }
-            __syncthreads();
-            real cr[8], cc[8];
+                    const real rs = rsqrt_real(d);
+                    const real ljj = d * rs;
 #pragma unroll
-            for (int a = 0; a < 8; ++a) { cr[a] = col[tr + 16 * a]; cc[a] = col[tc + 16 * a]; }
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-                if (16 * a + 15 > j) {
-#pragma unroll
-                    for (int b2 = 0; b2 <= a; ++b2)
-                        if (16 * b2 + 15 > j) a_[a][b2] -= cr[a] * cc[b2];
+                    for (int a = bj; a < 8; ++a) {
+                        const int r = tr + 16 * a;
+                        const real v = (r > j) ? a_[a][bj] * rs : ((r == j) ? ljj : a_[a][bj]);
+                        a_[a][bj] = v;
+                        col[r] = (r > j) ? v : (real)0;
+                    }
+                    if (tr == 0) {                            // the extra row: z_j = rhs_j / L[j][j]
+                        rr[bj] = rr[bj] * rs;
+                        col[TILE] = rr[bj];
+                    }
                 }
-            if (tr == 0) {
-                const real zj = col[TILE];
+                __syncthreads();
+                real cr[8], cc[8];
 #pragma unroll
-                for (int b2 = 0; b2 < 8; ++b2) rr[b2] -= zj * cc[b2];       // cc is 0 for columns <= j
-            }
-            // publish the next pivot's diagonal entry
-            if (j + 1 < TILE && tr == ((j + 1) & 15) && tc == ((j + 1) & 15)) {
-                const int bn = (j + 1) >> 4;
+                for (int a = bj; a < 8; ++a) { cr[a] = col[tr + 16 * a]; cc[a] = col[tc + 16 * a]; }
 #pragma unroll
-                for (int a = 0; a < 8; ++a)
-                    if (a == bn) sdiag = a_[a][a];
+                for (int a = bj; a < 8; ++a)
+#pragma unroll
+                    for (int b2 = bj; b2 <= a; ++b2) a_[a][b2] -= cr[a] * cc[b2];   // col[] is 0 for rows <= j
+                if (tr == 0) {
+                    const real zj = col[TILE];
+#pragma unroll
+                    for (int b2 = bj; b2 < 8; ++b2) rr[b2] -= zj * cc[b2];
+                }
+                // publish the next pivot's diagonal entry: A[j+1][j+1] lives in block (bj, bj), or in block
+                // (bj+1, bj+1) of thread (0, 0) when j+1 starts the next block
+                if (jj < 15) {
+                    if (tr == jj + 1 && tc == jj + 1) sdiag = a_[bj][bj];
+                } else if (bj < 7) {
+                    if (tid == 0) sdiag = a_[bj + 1 < 8 ? bj + 1 : 7][bj + 1 < 8 ? bj + 1 : 7];
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         // ---- L[kk] -> slab (lower; the strict upper part of the slab block is zeroed), the four diagonal
         //      32 x 32 blocks -> LDS for their inversion, z_k -> global
