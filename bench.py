@@ -237,7 +237,7 @@ def main():
 
     # ---------------------------------------------------------------- CPU baseline (oracle = port), rank 0
     cpu = None
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:          # the CPU leg runs on rank 0 of the single-GPU run only
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
         cores = min(16, os.cpu_count() or 1)

@@ -376,17 +376,40 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void chol_backsolve_kernel(const PatchDesc *__restrict__ descs,
                                                               const real *__restrict__ A, const real *__restrict__ ninv,
-                                                              const real *__restrict__ z, real *__restrict__ cvec)
+                                                              const real *__restrict__ z, real *__restrict__ cvec,
+                                                              int cs_in_lds)
 {
     const PatchDesc pd = descs[blockIdx.x];
-    extern __shared__ real sm[];
-    real *cs = sm;                  // ld : the solution so far
-    real *r = sm + pd.ld;           // TILE
+    extern __shared__ double sm_raw[];
+    real *sm = reinterpret_cast<real *>(sm_raw);
+    // LDS: the solution so far (ld), the right-hand side of the current block (TILE), the current diagonal tile
+    // L[kk] (padded leading dimension: the substitution walks columns, one thread per column) and its four
+    // negated inverted 32 x 32 blocks.  The tile used to be read from the slab inside the substitution: 32 threads
+    // chasing strided global loads cost ~60 us per block row, most of this kernel's time.
+    constexpr int LDN = SB + 1;
+    real *r = sm;
+    real *Lt = r + TILE;                 // the six 32 x 32 blocks of L[kk] below its block diagonal, ld 33
+    real *Nt = Lt + 6 * SB * LDN;
+    real *cs = cs_in_lds ? Nt + 4 * SB * LDN : cvec + pd.yoff;     // very long patches keep c in global memory
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const real *S = A + pd.aoff;
     const int64_t ld = pd.ld;
     for (int k = pd.nt - 1; k >= 0; --k) {
         const int64_t d0 = (int64_t)k * TILE;
+        // stage L[kk] and its -D^-1 blocks (coalesced), overlapping with the column dots below
+        {
+            const real *Lkk = S + d0 + d0 * ld;
+            for (int e = tid; e < 6 * SB * SB; e += 1024) {
+                const int b = e >> 10, i = e & 31, c = (e >> 5) & 31;
+                const int bi = (b >= 3) ? 3 : (b >= 1 ? 2 : 1), bs = b - bi * (bi - 1) / 2;   // block (bi, bs), bi > bs
+                Lt[b * (SB * LDN) + i + c * LDN] = Lkk[SB * bi + i + (int64_t)(SB * bs + c) * ld];
+            }
+            const real *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
+            for (int e = tid; e < 4 * SB * SB; e += 1024) {
+                const int s = e >> 10, i = e & 31, c = (e >> 5) & 31;
+                Nt[s * (SB * LDN) + i + c * LDN] = Ni[e];
+            }
+        }
         // r[col] = z_k[col] - sum_{i >= d0 + TILE} L[i, d0 + col] c[i]: one wave per column, coalesced rows
         const int64_t i0 = d0 + TILE;
         for (int cc = wave; cc < TILE; cc += 16) {
@@ -406,26 +429,29 @@ __global__ __launch_bounds__(1024) void chol_backsolve_kernel(const PatchDesc *_
             if (lane == 0) r[cc] = z[pd.yoff + d0 + cc] - s;
         }
         __syncthreads();
-        // c_k = L[kk]^-T r by block backward substitution with the negated inverted 32 x 32 blocks
-        const real *Lkk = S + d0 + d0 * ld;
-        const real *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
+        // c_k = L[kk]^-T r by block backward substitution with the negated inverted 32 x 32 blocks, all from LDS
         for (int s = 3; s >= 0; --s) {
             if (tid < SB) {
                 const int col = SB * s + tid;
                 real v = r[col];
-                for (int i = SB * (s + 1); i < TILE; ++i) v -= Lkk[i + (int64_t)col * ld] * cs[d0 + i];
+                for (int bi = s + 1; bi < 4; ++bi) {
+                    const real *blk = Lt + (bi * (bi - 1) / 2 + s) * (SB * LDN) + tid * LDN;
+                    for (int i = 0; i < SB; ++i) v -= blk[i] * cs[d0 + SB * bi + i];
+                }
                 r[col] = v;
             }
             __syncthreads();
             if (tid < SB) {
                 real v = 0.0;
-                for (int i = tid; i < SB; ++i) v -= Ni[1024 * s + i + 32 * tid] * r[SB * s + i];   // D^-T r
+                for (int i = tid; i < SB; ++i) v -= Nt[s * (SB * LDN) + i + tid * LDN] * r[SB * s + i];   // D^-T r
                 cs[d0 + SB * s + tid] = v;
             }
+            __threadfence_block();
             __syncthreads();
         }
     }
-    for (int i = tid; i < pd.ld; i += 1024) cvec[pd.yoff + i] = cs[i];
+    if (cs_in_lds)
+        for (int i = tid; i < pd.ld; i += 1024) cvec[pd.yoff + i] = cs[i];
 }
 
 template <int D, int FAM, int FUSE>
@@ -513,9 +539,18 @@ int launch_ninv_from_slabs(pmk_model *m, hipStream_t s)
 
 int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 {
-    const size_t lds = sizeof(real) * ((size_t)m->max_nt * TILE + TILE);
+    const size_t fixed = sizeof(real) * (TILE + 10 * SB * (SB + 1));
+    const size_t csb = sizeof(real) * (size_t)m->max_nt * TILE;
+    const int cs_in_lds = fixed + csb <= 150 * 1024;
+    const size_t lds = fixed + (cs_in_lds ? csb : 0);
+    static bool attr_set = false;
+    if (!attr_set) {      // more than the default 64 KB of dynamic LDS
+        PMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_backsolve_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
     hipLaunchKernelGGL(chol_backsolve_kernel, dim3((unsigned)np), dim3(1024), lds, s, m->d_desc + p0, (real *)m->d_a, (real *)m->d_inv,
-                       (real *)m->d_z, (real *)m->d_c);
+                       (real *)m->d_z, (real *)m->d_c, cs_in_lds);
     PMK_HIP(hipGetLastError());
     return 0;
 }
