@@ -133,7 +133,7 @@ def main():
     model.set_bsp(root, lo)
     Nq = args.nq * world
     Xq = rng.uniform(0, 1, (Nq, 3)) if cfgE else np.stack([rng.uniform(-5, 5, Nq), rng.uniform(-10, 10, Nq)], 1)
-    query = pmk.DeviceQuery(model, Xq)                                  # plan is replicated; items are sharded
+    query = pmk.DeviceQuery(model, Xq[rank * args.nq:(rank + 1) * args.nq])   # queries are sharded like the leaves
 
     def sync():
         torch.cuda.synchronize()
@@ -181,10 +181,9 @@ def main():
     from patchmixturekriging_amd import dist as pdist
 
     def predict_step():
-        # plan (K5 + sort, replicated) -> items of the owned regions (K4) -> ONE all-gather of (u, v) over
-        # RCCL/xGMI -> mixture (K6) on this rank's slice of the queries
-        return pdist.sharded_predict(query, th, wth, radius, delta, P * world, rank, world,
-                                     nq_slice=(rank * args.nq, (rank + 1) * args.nq))
+        # plan of this rank's queries (K5 + sort) -> all-to-all of the (point, region) requests to the leaf owners ->
+        # items (K4) -> all-to-all of (u, v) back (RCCL/xGMI) -> mixture (K6)
+        return pdist.sharded_predict(query, th, wth, radius, delta, P * world, rank, world)
 
     ctx.L.pmk_ctx_enable_timers(ctx.h, 0)
     total_items = predict_step()
@@ -199,8 +198,7 @@ def main():
         except pmk.PmkError:
             pass
     Yq, Vq = query.fetch()
-    sl = slice(rank * args.nq, (rank + 1) * args.nq)
-    assert nocheck or (np.all(np.isfinite(Yq[sl])) and np.all(Vq[sl] >= 1e-12))
+    assert nocheck or (np.all(np.isfinite(Yq)) and np.all(Vq >= 1e-12))
 
     if rank != 0:
         if world > 1:
@@ -302,8 +300,8 @@ def main():
                                 "mixGP 2-D Spline34(1/15), %d BSP patches x %d points per GPU, sigma2=1e-5 (BASELINE config C)")
                                % (P, n),
                    "patches_per_gpu": P, "points_per_patch": n, "patch_sizes_minmax": [min(sizes), max(sizes)],
-                   "queries_per_gpu": args.nq, "radius": radius, "items_per_query": total_items / Nq,
-                   "levels": levels, "parallelism": "leaves sharded %d per GPU; one all-gather of (u,v)" % P,
+                   "queries_per_gpu": args.nq, "radius": radius, "items_per_query": total_items / args.nq,
+                   "levels": levels, "parallelism": "leaves and queries sharded (%d leaves per GPU); all-to-all of requests and of (u,v)" % P,
                    "bsp_build_s_host": t_bsp},
         "stage_ms": {**stage, **{"predict_" + k: v for k, v in pstage.items()}},
         "roofline": roof,

@@ -160,7 +160,7 @@ int  pmk_model_queryinner(pmk_model *m, int64_t patch, const pmk_kernel_desc *th
 /* ---- predict -------------------------------------------------------------------------- */
 /* attach the tree; this model holds the global leaves [leaf_base, leaf_base + P) */
 int  pmk_model_set_bsp(pmk_model *m, const pmk_bsp *bsp, int64_t leaf_base);
-/* upload Nq query points */
+/* upload Nq query points (Xq: host or device pointer, point-major Nq x D) */
 int  pmk_query_create(pmk_model *m, int64_t Nq, const double *Xq, pmk_query **out);
 /* stage 1: home leaf (partition.jl:248-262) + neighbour items (mixtureGP.jl:339-405) for
  * every query, items sorted by region (stable).  Blocks (sizes come back to the host). */
@@ -175,6 +175,17 @@ int  pmk_query_items(pmk_query *q, const pmk_kernel_desc *th);
 /* device pointers of the per-item results in sorted order (length total_items each); a
  * multi-GPU caller all-gathers the owned segments into them between stage 2 and 3 */
 int  pmk_query_item_buffers(pmk_query *q, void **u_dev, void **v_dev);
+/* ---- multi-GPU, queries sharded over ranks: a rank plans only its own queries against the
+ * global tree, sends the (point, region) requests of every sorted-list segment to the rank that owns those leaves,
+ * which evaluates queryinner! for them and sends (u, v) back into the requester's item buffers.
+ * requests of the sorted items [first, first + n) -> DEVICE arrays xq_dev [n x D point-major], region_dev [n] */
+int  pmk_query_export_requests(pmk_query *q, int64_t first, int64_t n, double *xq_dev, int32_t *region_dev);
+/* a planned batch of n explicit (point, region) items, one per point (host or device pointers); every region must
+ * lie in this model's leaves (-3 otherwise).  Follow with pmk_query_items + pmk_query_export_results. */
+int  pmk_query_create_items(pmk_model *m, int64_t n, const double *xq, const int32_t *region, pmk_query **out);
+/* (u, v) of all items in item order (the order given to pmk_query_create_items; reference order for a planned
+ * query) -> DEVICE arrays of length total_items (either may be NULL).  Enqueues. */
+int  pmk_query_export_results(pmk_query *q, double *u_dev, double *v_dev);
 /* stage 3: mixture weights and blend (mixtureGP.jl:224-272) for queries [q0, q1).  Enqueues. */
 int  pmk_query_mix(pmk_query *q, const pmk_kernel_desc *weight_th, int64_t q0, int64_t q1);
 /* blocks; Yq, Vq [Nq] (either may be NULL) */

@@ -80,6 +80,9 @@ SIGNATURES = {
     "pmk_model_queryinner": (C.c_int, [_vp, C.c_int64, _kp, C.c_int64, _dp, _dp, _dp]),
     "pmk_model_set_bsp": (C.c_int, [_vp, _vp, C.c_int64]),
     "pmk_query_create": (C.c_int, [_vp, C.c_int64, _dp, _vpp]),
+    "pmk_query_create_items": (C.c_int, [_vp, C.c_int64, C.c_void_p, C.c_void_p, _vpp]),
+    "pmk_query_export_requests": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pmk_query_export_results": (C.c_int, [_vp, C.c_void_p, C.c_void_p]),
     "pmk_query_plan": (C.c_int, [_vp, C.c_double, C.c_double]),
     "pmk_query_counts": (C.c_int, [_vp, _ip, _ip, _ip]),
     "pmk_query_region_offsets": (C.c_int, [_vp, _ip]),

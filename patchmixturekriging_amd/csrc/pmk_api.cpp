@@ -684,6 +684,28 @@ void pmk_query_destroy(pmk_query *q)
     delete q;
 }
 
+// per-item buffers, grow only: repeated plans of one query batch reuse them
+static int grow_item_buffers(pmk_query *q, int64_t total)
+{
+    if (total <= q->item_cap) return 0;
+    dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
+    dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w);
+    q->item_cap = 0;
+    const int64_t cap = total + total / 8 + 1024;
+    int rc = 0;
+    rc |= dev_alloc(&q->d_item_region, cap);
+    rc |= dev_alloc(&q->d_item_t, cap);
+    rc |= dev_alloc(&q->d_item_query, cap);
+    rc |= dev_alloc(&q->d_sorted_item, cap);
+    rc |= dev_alloc(&q->d_item_pos, cap);
+    rc |= dev_alloc(&q->d_u, cap);
+    rc |= dev_alloc(&q->d_v, cap);
+    rc |= dev_alloc(&q->d_w, cap);
+    if (rc) return -100;
+    q->item_cap = cap;
+    return 0;
+}
+
 int pmk_query_create(pmk_model *m, int64_t Nq, const double *Xq, pmk_query **out)
 {
     if (!out) { set_error("pmk_query_create: out is NULL"); return -4; }
@@ -704,9 +726,69 @@ int pmk_query_create(pmk_model *m, int64_t Nq, const double *Xq, pmk_query **out
     rc |= dev_alloc(&q->d_yq, Nq);
     rc |= dev_alloc(&q->d_vq, Nq);
     if (rc) { pmk_query_destroy(q); return -100; }
-    if (Nq > 0) PMK_HIP(hipMemcpy(q->d_xq, Xq, sizeof(double) * (size_t)(Nq * m->D), hipMemcpyHostToDevice));
+    if (Nq > 0) PMK_HIP(hipMemcpy(q->d_xq, Xq, sizeof(double) * (size_t)(Nq * m->D), hipMemcpyDefault));
     *out = q;
     return 0;
+}
+
+int pmk_query_create_items(pmk_model *m, int64_t n, const double *xq, const int32_t *region, pmk_query **out)
+{
+    if (!out) { set_error("pmk_query_create_items: out is NULL"); return -4; }
+    *out = nullptr;
+    if (n > 0 && !region) { set_error("pmk_query_create_items: region is NULL"); return -2; }
+    pmk_query *q = nullptr;
+    int rc = pmk_query_create(m, n, xq, &q);
+    if (rc) return rc;
+    pmk_ctx *c = m->ctx;
+    hipStream_t s = c->stream;
+    q->total = n;
+    q->roff.assign((size_t)(m->P_global + 1), 0);
+    if (n > 0) {
+        int *d_bad = nullptr;
+        int bad = 0;
+        if ((rc = grow_item_buffers(q, n)) || (rc = dev_alloc(&d_bad, 1))) { pmk_query_destroy(q); return -100; }
+        hipError_t e = hipMemcpyAsync(q->d_item_region, region, sizeof(int32_t) * (size_t)n, hipMemcpyDefault, s);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), s);
+        if (e == hipSuccess) rc = launch_explicit_items(q, d_bad, s);
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(s);
+        dev_free(d_bad);
+        if (e != hipSuccess) { set_error("pmk_query_create_items: %s", hipGetErrorString(e)); rc = -100; }
+        if (!rc && bad) {
+            set_error("pmk_query_create_items: a region is outside this model's leaves [%lld, %lld)",
+                      (long long)m->leaf_base, (long long)(m->leaf_base + m->P));
+            rc = -3;
+        }
+        if (!rc) rc = launch_sort_items(q, s);
+        if (!rc) {
+            e = hipMemcpyAsync(q->roff.data(), q->d_roff, sizeof(int64_t) * q->roff.size(), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { set_error("pmk_query_create_items: %s", hipGetErrorString(e)); rc = -100; }
+        }
+        if (!rc) rc = PMK_BY_DTYPE(m, build_strip_tasks(q, s));
+        if (rc) { pmk_query_destroy(q); return rc; }
+    }
+    q->planned = true;
+    *out = q;
+    return 0;
+}
+
+int pmk_query_export_requests(pmk_query *q, int64_t first, int64_t n, double *xq_dev, int32_t *region_dev)
+{
+    if (!q || !q->planned) { set_error("pmk_query_export_requests: query is not planned"); return -1; }
+    if (first < 0 || n < 0 || first + n > q->total) { set_error("pmk_query_export_requests: bad item range"); return -3; }
+    if (n > 0 && (!xq_dev || !region_dev)) { set_error("pmk_query_export_requests: NULL output"); return -2; }
+    pmk_ctx *c = q->m->ctx;
+    PMK_HIP(hipSetDevice(c->device));
+    return launch_export_requests(q, first, n, xq_dev, region_dev, c->stream);
+}
+
+int pmk_query_export_results(pmk_query *q, double *u_dev, double *v_dev)
+{
+    if (!q || !q->planned) { set_error("pmk_query_export_results: query is not planned"); return -1; }
+    pmk_ctx *c = q->m->ctx;
+    PMK_HIP(hipSetDevice(c->device));
+    return launch_export_results(q, u_dev, v_dev, c->stream);
 }
 
 int pmk_query_plan(pmk_query *q, double radius, double delta)
@@ -731,23 +813,7 @@ int pmk_query_plan(pmk_query *q, double radius, double delta)
         PMK_HIP(hipMemcpyAsync(&q->total, q->d_qoff + q->Nq, sizeof(int64_t), hipMemcpyDeviceToHost, s));
         PMK_HIP(hipStreamSynchronize(s));
         if (q->total > 0x7fffffff) { set_error("pmk_query_plan: too many work items (%lld)", (long long)q->total); return -5; }
-        if (q->total > q->item_cap) {          // grow only: repeated plans of one query batch reuse the buffers
-            dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
-            dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w);
-            q->item_cap = 0;
-            const int64_t cap = q->total + q->total / 8 + 1024;
-            rc = 0;
-            rc |= dev_alloc(&q->d_item_region, cap);
-            rc |= dev_alloc(&q->d_item_t, cap);
-            rc |= dev_alloc(&q->d_item_query, cap);
-            rc |= dev_alloc(&q->d_sorted_item, cap);
-            rc |= dev_alloc(&q->d_item_pos, cap);
-            rc |= dev_alloc(&q->d_u, cap);
-            rc |= dev_alloc(&q->d_v, cap);
-            rc |= dev_alloc(&q->d_w, cap);
-            if (rc) return -100;
-            q->item_cap = cap;
-        }
+        if ((rc = grow_item_buffers(q, q->total))) return rc;
         if ((rc = launch_plan_fill(q, radius, delta, s))) return rc;
         if ((rc = launch_sort_items(q, s))) return rc;
         PMK_HIP(hipMemcpyAsync(q->roff.data(), q->d_roff, sizeof(int64_t) * q->roff.size(), hipMemcpyDeviceToHost, s));

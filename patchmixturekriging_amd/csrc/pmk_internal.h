@@ -157,6 +157,9 @@ int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_plan_fill(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_sort_items(pmk_query *q, hipStream_t s);
 int launch_mix(pmk_query *q, const pmk_kernel_desc &wth, int64_t q0, int64_t q1, hipStream_t s);
+int launch_export_requests(pmk_query *q, int64_t first, int64_t n, double *x_out, int32_t *region_out, hipStream_t s);
+int launch_export_results(pmk_query *q, double *u_out, double *v_out, hipStream_t s);
+int launch_explicit_items(pmk_query *q, int *d_bad, hipStream_t s);
 int launch_query_mean(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
                       const double *d_c, int64_t nq, const double *d_xq, double *d_yq, hipStream_t s);
 int64_t exclusive_scan_i32_to_i64(const int32_t *d_in, int64_t *d_out, int64_t n, void **tmp, size_t *tmp_bytes,

@@ -293,6 +293,84 @@ int launch_sort_items(pmk_query *q, hipStream_t s)
     return 0;
 }
 
+// ---- multi-GPU request/response helpers (query-sharded predict) ----
+// requests of the sorted items [first, first + n): coordinates (point-major) and global region
+template <int D>
+__global__ void export_requests_kernel(int64_t first, int64_t n, const int32_t *__restrict__ sorted_item,
+                                       const int32_t *__restrict__ item_query, const int32_t *__restrict__ item_region,
+                                       const double *__restrict__ xq, double *__restrict__ x_out,
+                                       int32_t *__restrict__ region_out)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int32_t it = sorted_item[first + k];
+    const int64_t j = item_query[it];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x_out[k * D + d] = xq[j * D + d];
+    region_out[k] = item_region[it];
+}
+
+int launch_export_requests(pmk_query *q, int64_t first, int64_t n, double *x_out, int32_t *region_out, hipStream_t s)
+{
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    switch (q->m->D) {
+    case 1: hipLaunchKernelGGL(export_requests_kernel<1>, grid, block, 0, s, first, n, q->d_sorted_item, q->d_item_query, q->d_item_region, q->d_xq, x_out, region_out); break;
+    case 2: hipLaunchKernelGGL(export_requests_kernel<2>, grid, block, 0, s, first, n, q->d_sorted_item, q->d_item_query, q->d_item_region, q->d_xq, x_out, region_out); break;
+    case 3: hipLaunchKernelGGL(export_requests_kernel<3>, grid, block, 0, s, first, n, q->d_sorted_item, q->d_item_query, q->d_item_region, q->d_xq, x_out, region_out); break;
+    case 4: hipLaunchKernelGGL(export_requests_kernel<4>, grid, block, 0, s, first, n, q->d_sorted_item, q->d_item_query, q->d_item_region, q->d_xq, x_out, region_out); break;
+    default: set_error("input dimension %d not supported", q->m->D); return -2;
+    }
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// (u, v) back into item (reference) order
+__global__ void export_results_kernel(int64_t n, const int32_t *__restrict__ item_pos, const double *__restrict__ u,
+                                      const double *__restrict__ v, double *__restrict__ u_out, double *__restrict__ v_out)
+{
+    const int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (it >= n) return;
+    const int32_t pos = item_pos[it];
+    if (u_out) u_out[it] = u[pos];
+    if (v_out) v_out[it] = v[pos];
+}
+
+int launch_export_results(pmk_query *q, double *u_out, double *v_out, hipStream_t s)
+{
+    if (q->total == 0) return 0;
+    hipLaunchKernelGGL(export_results_kernel, dim3((unsigned)((q->total + 255) / 256)), dim3(256), 0, s, q->total,
+                       q->d_item_pos, q->d_u, q->d_v, u_out, v_out);
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// explicit items: one item per point; flag regions outside [lo, hi)
+__global__ void explicit_items_kernel(int64_t n, const int32_t *__restrict__ region, int32_t lo, int32_t hi,
+                                      int32_t *__restrict__ item_query, double *__restrict__ item_t,
+                                      int64_t *__restrict__ qoff, int32_t *__restrict__ home, int *__restrict__ bad)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k > n) return;
+    qoff[k] = k;
+    if (k == n) return;
+    item_query[k] = (int32_t)k;
+    item_t[k] = 0.0;
+    const int32_t r = region[k];
+    home[k] = r;
+    if (r < lo || r >= hi) atomicOr(bad, 1);
+}
+
+int launch_explicit_items(pmk_query *q, int *d_bad, hipStream_t s)
+{
+    const pmk_model *m = q->m;
+    hipLaunchKernelGGL(explicit_items_kernel, dim3((unsigned)((q->Nq + 256) / 256)), dim3(256), 0, s, q->Nq,
+                       q->d_item_region, (int32_t)m->leaf_base, (int32_t)(m->leaf_base + m->P), q->d_item_query,
+                       q->d_item_t, q->d_qoff, q->d_home, d_bad);
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
 // =============================================================================================
 // K6: mixture weights and blend, src/RKHS/mixtureGP.jl:224-272.  Neighbour weights phi_w(|t|) in
 // hyperplane order, home weight 1 last, normalise, Yq = sum w u, Vq = sum w (v w).

@@ -1,11 +1,15 @@
 """Multi-GPU sharding of the path.
 
 Fit: leaves are independent -> rank r owns the contiguous leaves [r P/G, (r+1) P/G) (= one depth-log2(G)
-subtree of the BSP); no communication.  Predict: the work-item plan is replicated (every rank derives
-the same stably sorted item list from the same tree and queries), each rank fills the (u, v) of the
-items whose region it owns -- one contiguous segment of the sorted list -- and ONE all-gather of the
-segments (RCCL over xGMI on GPUs; gloo in the CPU tests) completes the arrays before every rank blends
-its own slice of the queries.
+subtree of the BSP); no communication.
+
+Predict: queries are sharded too.  Every rank plans ITS OWN queries against the replicated tree (the plan is
+O(queries x hyperplanes), so a replicated plan would grow with the square of the job), which leaves it with a
+region-sorted list of (query, region) items.  Leaves are sharded contiguously, so the items a given rank owns form
+one contiguous segment of that list: ONE all-to-all (RCCL over xGMI on GPUs; gloo in the CPU tests) carries the
+(point, region) requests of each segment to the owning rank, the owner evaluates queryinner! for everything it
+received, and one all-to-all with the transposed counts carries (u, v) back into the requester's item buffers,
+after which the requester blends its queries locally.
 
 torch.distributed is plumbing here: the functions take tensors on whatever device the process group's
 backend handles.
@@ -37,29 +41,55 @@ def segments(region_offsets, world):
     return out
 
 
-def exchange_items(full, region_offsets, rank, world, group=None):
-    """Complete `full` (1-D tensor over all sorted items, this rank's segment already filled) with the
-    other ranks' segments: one all_gather_into_tensor of equal-padded slices.  Returns `full`."""
+def _comm_device(group=None):
+    import torch.distributed as dist
+    return "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+
+def exchange_counts(send_rows, world, group=None):
+    """send_rows[o] = rows this rank sends to rank o  ->  recv_rows[s] = rows rank s sends to this rank"""
     import torch
     import torch.distributed as dist
-    if world == 1:
-        return full
-    seg = segments(region_offsets, world)
-    mx = max(1, max(n for _, n in seg))
-    s0, n0 = seg[rank]
-    send = torch.zeros(mx, dtype=full.dtype, device=full.device)
-    send[:n0] = full[s0:s0 + n0]
-    gathered = torch.empty(world * mx, dtype=full.dtype, device=full.device)
-    try:
-        dist.all_gather_into_tensor(gathered, send, group=group)
-    except (RuntimeError, NotImplementedError):
-        # backends without allgather_base (gloo in the CPU tests / rehearsals): list form, same bytes
-        parts = [gathered[r * mx:(r + 1) * mx] for r in range(world)]
-        dist.all_gather(parts, send, group=group)
-    for r, (s, n) in enumerate(seg):
-        if r != rank and n:
-            full[s:s + n] = gathered[r * mx:r * mx + n]
-    return full
+    dev = _comm_device(group)
+    mine = torch.tensor([int(n) for n in send_rows], dtype=torch.int64, device=dev)
+    table = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(table, mine, group=group)
+    rank = dist.get_rank(group)
+    return [int(table[s][rank]) for s in range(world)]
+
+
+def all_to_all_rows(out, inp, out_rows, in_rows, group=None):
+    """all_to_all_single over dim 0 with per-rank row counts.  gloo has no device path: device tensors are staged
+    through the host for it (one-box rehearsals)."""
+    import torch
+    import torch.distributed as dist
+    if _comm_device(group) == "cpu" and inp.is_cuda:
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu(), list(out_rows), list(in_rows), group=group)
+        out.copy_(host)
+    else:
+        dist.all_to_all_single(out, inp, list(out_rows), list(in_rows), group=group)
+    return out
+
+
+def route_requests(xs, rg, send_rows, world, group=None):
+    """xs [total, D] / rg [total]: this rank's requests grouped by owning rank (send_rows[o] rows for rank o, in rank
+    order -- the region-sorted item list already is).  Returns (rx, rr, recv_rows): what this rank must evaluate,
+    grouped by requesting rank."""
+    import torch
+    recv_rows = exchange_counts(send_rows, world, group)
+    n = sum(recv_rows)
+    rx = torch.empty((n, xs.shape[1]), dtype=xs.dtype, device=xs.device)
+    rr = torch.empty(n, dtype=rg.dtype, device=rg.device)
+    all_to_all_rows(rx, xs, recv_rows, send_rows, group)
+    all_to_all_rows(rr, rg, recv_rows, send_rows, group)
+    return rx, rr, recv_rows
+
+
+def return_results(ru, rv, u_out, v_out, send_rows, recv_rows, group=None):
+    """the transposed exchange: results of the received requests back into the requesters' sorted item order"""
+    all_to_all_rows(u_out, ru, send_rows, recv_rows, group)
+    all_to_all_rows(v_out, rv, send_rows, recv_rows, group)
 
 
 class DevArray:
@@ -69,18 +99,40 @@ class DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def sharded_predict(query, theta, weight_theta, radius, delta, P_global, rank, world, nq_slice=None, group=None):
-    """One predict step of a sharded model (see bench.py): plan (replicated), items (owned regions),
-    all-gather of (u, v), mixture on this rank's slice of the queries.  Returns the item count."""
+def sharded_predict(query, theta, weight_theta, radius, delta, P_global, rank, world, group=None):
+    """One predict step of a sharded model (see bench.py).  `query` holds THIS rank's queries; the model behind it
+    holds the leaves leaf_range(rank, world, P_global).  plan (own queries) -> requests to the owners -> items ->
+    results back -> mixture.  Returns this rank's item count."""
     import torch
+    from .mixture import DeviceQuery
     total = query.plan(radius, delta)
-    query.items(theta)
-    if world > 1 and total > 0:
-        off = query.region_offsets(P_global)
-        u_ptr, v_ptr = query.item_buffers()
-        for ptr in (u_ptr, v_ptr):
-            full = torch.as_tensor(DevArray(ptr, total), device="cuda")
-            exchange_items(full, off, rank, world, group)
-    q0, q1 = nq_slice if nq_slice is not None else query_range(rank, world, query.Nq)
-    query.mix(weight_theta, q0, q1)
+    if world == 1:
+        query.items(theta)
+        query.mix(weight_theta)
+        return total
+    model, ctx = query.model, query.model.ctx
+    off = query.region_offsets(P_global)
+    send_rows = [n for _, n in segments(off, world)]
+    xs = torch.empty((total, model.D), dtype=torch.float64, device="cuda")
+    rg = torch.empty(total, dtype=torch.int32, device="cuda")
+    query.export_requests(0, total, xs.data_ptr(), rg.data_ptr())
+    ctx.synchronize()                                   # library stream -> torch / RCCL
+    rx, rr, recv_rows = route_requests(xs, rg, send_rows, world, group)
+    torch.cuda.synchronize()
+    remote = DeviceQuery.from_items(model, rx.shape[0], rx.data_ptr(), rr.data_ptr())
+    remote.items(theta)
+    ru = torch.empty(rx.shape[0], dtype=torch.float64, device="cuda")
+    rv = torch.empty(rx.shape[0], dtype=torch.float64, device="cuda")
+    remote.export_results(ru.data_ptr(), rv.data_ptr())
+    ctx.synchronize()
+    u_ptr, v_ptr = query.item_buffers()
+    if total > 0:
+        u_out = torch.as_tensor(DevArray(u_ptr, total), device="cuda")
+        v_out = torch.as_tensor(DevArray(v_ptr, total), device="cuda")
+    else:
+        u_out = torch.empty(0, dtype=torch.float64, device="cuda")
+        v_out = torch.empty(0, dtype=torch.float64, device="cuda")
+    return_results(ru, rv, u_out, v_out, send_rows, recv_rows, group)
+    torch.cuda.synchronize()
+    query.mix(weight_theta)
     return total

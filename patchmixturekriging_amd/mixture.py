@@ -139,10 +139,31 @@ class DeviceQuery:
         self.h = h
         self.L = model.ctx.L
 
+    @classmethod
+    def from_items(cls, model, n, xq_ptr, region_ptr):
+        """pmk_query_create_items: n explicit (point, region) items received from other ranks; xq_ptr / region_ptr
+        are raw host or device addresses (float64 n x D point-major, int32 n)"""
+        self = cls.__new__(cls)
+        self.model, self.Xq, self.Nq, self.L = model, None, int(n), model.ctx.L
+        h = C.c_void_p()
+        _lib.check(self.L.pmk_query_create_items(model.h, int(n), xq_ptr, region_ptr, C.byref(h)), "pmk_query_create_items")
+        self.h = h
+        self.total, self.first_owned, self.num_owned = int(n), 0, int(n)
+        return self
+
     def __del__(self):
         if getattr(self, "h", None):
             self.L.pmk_query_destroy(self.h)
             self.h = None
+
+    def export_requests(self, first, n, xq_dev_ptr, region_dev_ptr):
+        """(point, region) of the sorted items [first, first + n) into caller-owned device arrays"""
+        _lib.check(self.L.pmk_query_export_requests(self.h, int(first), int(n), xq_dev_ptr, region_dev_ptr),
+                   "pmk_query_export_requests")
+
+    def export_results(self, u_dev_ptr, v_dev_ptr):
+        """(u, v) in item order into caller-owned device arrays of length `total`"""
+        _lib.check(self.L.pmk_query_export_results(self.h, u_dev_ptr, v_dev_ptr), "pmk_query_export_results")
 
     def plan(self, radius, delta):
         _lib.check(self.L.pmk_query_plan(self.h, float(radius), float(delta)), "pmk_query_plan")

@@ -1,6 +1,7 @@
 """The N>1 path on CPU: world_size-2 (and 4) gloo process groups exercise the sharding arithmetic and the
-one exchange step of the predict path (patchmixturekriging_amd/dist.py) with the oracle standing in for the
-per-item GPU kernel, and check the blended result against the single-process oracle."""
+request/response exchange of the predict path (patchmixturekriging_amd/dist.py: every rank plans its own
+queries, all-to-all of the requests to the leaf owners, all-to-all of (u, v) back) with the oracle standing in for
+the per-item GPU kernel, and check the blended result against the single-process oracle."""
 import os
 import socket
 import sys
@@ -55,10 +56,13 @@ def _worker(rank, world, port, tmp):
         oth, owth = O.kernel(O.SPLINE34, a), O.kernel(O.SPLINE34, 1 / radius)
         lo, hi = pd.leaf_range(rank, world, P)
         fits = {r: O.fit_patch(oth, X_set[r], y[X_set_inds[r]], sigma2) for r in range(lo, hi)}   # fit: no comm
-        # replicated plan = what pmk_query_plan produces: items in reference order, stably sorted by region
+        # this rank's queries only; the plan = what pmk_query_plan produces: items in reference order, stably
+        # sorted by region
+        q0, q1 = pd.query_range(rank, world, len(Xq))
+        Xl = Xq[q0:q1]
         hps = pmk.fetchhyperplanes(root)
         item_q, item_r, item_t, qoff = [], [], [], [0]
-        for j, x in enumerate(Xq):
+        for j, x in enumerate(Xl):
             home = pmk.findpartition(x, root)
             reg, ts, _, keep = pmk.findneighbourpartitions(x, radius, root, levels, hps, home, delta=delta)
             item_q += [j] * (len(reg) + 1); item_r += list(reg) + [home]; item_t += list(ts[keep]) + [0.0]
@@ -68,25 +72,29 @@ def _worker(rank, world, port, tmp):
         roff = np.concatenate([[0], np.cumsum(np.bincount(item_r, minlength=P))])
         pos = np.empty(len(order), dtype=np.int64); pos[order] = np.arange(len(order))
         total = len(order)
+        send_rows = [n for _, n in pd.segments(roff, world)]
+        assert sum(send_rows) == total
+        xs = torch.from_numpy(np.ascontiguousarray(Xl[item_q[order]]))           # requests in sorted order
+        rg = torch.from_numpy(item_r[order].astype(np.int32))
+        rx, rr, recv_rows = pd.route_requests(xs, rg, send_rows, world)           # all-to-all #1
+        assert rx.shape[0] == sum(recv_rows) and ((rr >= lo) & (rr < hi)).all()
+        ru = torch.empty(rx.shape[0], dtype=torch.float64)
+        rv = torch.empty(rx.shape[0], dtype=torch.float64)
+        for k in range(rx.shape[0]):                                   # items of the owned regions only
+            r_ = int(rr[k]); f = fits[r_]
+            mu, var = O.queryinner(oth, X_set[r_], f["c_lu"], f["L"], rx[k].numpy())
+            ru[k], rv[k] = mu, var
         u = torch.full((total,), float("nan"), dtype=torch.float64)
         v = torch.full((total,), float("nan"), dtype=torch.float64)
-        s0, n0 = pd.segments(roff, world)[rank]
-        for k in range(s0, s0 + n0):                                   # items of the owned regions only
-            it = order[k]
-            f = fits[item_r[it]]
-            mu, var = O.queryinner(oth, X_set[item_r[it]], f["c_lu"], f["L"], Xq[item_q[it]])
-            u[k], v[k] = mu, var
-        pd.exchange_items(u, roff, rank, world)                        # the path's one collective
-        pd.exchange_items(v, roff, rank, world)
+        pd.return_results(ru, rv, u, v, send_rows, recv_rows)                     # all-to-all #2
         assert not torch.isnan(u).any() and not torch.isnan(v).any()
-        q0, q1 = pd.query_range(rank, world, len(Xq))
         Yq, Vq = np.empty(q1 - q0), np.empty(q1 - q0)
-        for j in range(q0, q1):                                        # mixture on this rank's query slice
+        for j in range(q1 - q0):                                       # mixture on this rank's queries
             its = np.arange(qoff[j], qoff[j + 1])
             w = np.array([O.profile(owth, abs(t)) for t in item_t[its[:-1]]] + [1.0])
             w = w / w.sum()
-            Yq[j - q0] = w @ u[pos[its]].numpy()
-            Vq[j - q0] = w @ (v[pos[its]].numpy() * w)
+            Yq[j] = w @ u[pos[its]].numpy()
+            Vq[j] = w @ (v[pos[its]].numpy() * w)
         np.savez(os.path.join(tmp, "rank%d.npz" % rank), Yq=Yq, Vq=Vq, q0=q0, q1=q1)
         dist.barrier()
     finally:

@@ -425,9 +425,10 @@ def test_config_C_full_size_properties():
 
 # ------------------------------------------------------------------------------------ sharded predict (one process)
 def test_sharded_models_match_single_model():
-    """Two models that each own half of the leaves (what two ranks hold), the staged C-ABI calls with
-    leaf_base != 0, and the segment exchange of patchmixturekriging_amd.dist done by device copies: the blended
-    result must equal the single-model result bit for bit (same kernels, same order)."""
+    """Two models that each own half of the leaves and half of the queries (what two ranks hold): the staged C-ABI
+    calls with leaf_base != 0 and the request/response exchange of patchmixturekriging_amd.dist, with the two
+    all-to-alls done by device copies.  Every (query, region) item is evaluated by the same kernel on the same
+    operands whichever strip it lands in, so the blended result must equal the single-model result bit for bit."""
     import torch
     from patchmixturekriging_amd import dist as pd
     X, y, Xq = _mixgp_case(4000, 4, 0.5, 1 / 4.0, 1e-5, 0.6, 1e-5, 1500, 11)
@@ -441,34 +442,54 @@ def test_sharded_models_match_single_model():
     q = pmk.DeviceQuery(full, Xq); total = q.plan(radius, delta); q.items(th); q.mix(wth)
     Y0, V0 = q.fetch()
     world = 2
-    models, queries = [], []
+    models, queries, sends, reqs = [], [], [], []
     for r in range(world):
         lo, hi = pd.leaf_range(r, world, P)
         m = pmk.DeviceModel(X_set[lo:hi], ys[lo:hi]); m.fit(th, 1e-5); m.set_bsp(root, lo)
-        qq = pmk.DeviceQuery(m, Xq)
-        assert qq.plan(radius, delta) == total            # replicated, deterministic plan
-        qq.items(th)
-        models.append(m); queries.append(qq)
-    off = queries[0].region_offsets(P)
-    assert np.array_equal(off, queries[1].region_offsets(P)) and np.array_equal(off, q.region_offsets(P))
-    seg = pd.segments(off, world)
-    assert (queries[0].first_owned, queries[0].num_owned) == seg[0] and (queries[1].first_owned, queries[1].num_owned) == seg[1]
+        q0, q1 = pd.query_range(r, world, len(Xq))
+        qq = pmk.DeviceQuery(m, Xq[q0:q1])
+        n = qq.plan(radius, delta)
+        seg = pd.segments(qq.region_offsets(P), world)
+        assert (qq.first_owned, qq.num_owned) == seg[r] and sum(k for _, k in seg) == n
+        xs = torch.empty((n, 2), dtype=torch.float64, device="cuda")
+        rg = torch.empty(n, dtype=torch.int32, device="cuda")
+        qq.export_requests(0, n, xs.data_ptr(), rg.data_ptr())
+        models.append(m); queries.append(qq); sends.append(seg); reqs.append((xs, rg))
+    assert sum(qq.total for qq in queries) == total
     pmk.default_context().synchronize()
-    bufs = [[torch.as_tensor(pd.DevArray(p, total), device="cuda") for p in qq.item_buffers()] for qq in queries]
-    for r in range(world):                                # what the all-gather does
-        for o in range(world):
-            if o != r:
-                s0, n0 = seg[o]
-                for a in range(2):
-                    bufs[r][a][s0:s0 + n0] = bufs[o][a][s0:s0 + n0]
+    bufs = [[torch.as_tensor(pd.DevArray(p, qq.total), device="cuda") for p in qq.item_buffers()] for qq in queries]
+    for o in range(world):                                # owner o: what the first all-to-all delivers
+        rx = torch.cat([reqs[s][0][sends[s][o][0]:sends[s][o][0] + sends[s][o][1]] for s in range(world)])
+        rr = torch.cat([reqs[s][1][sends[s][o][0]:sends[s][o][0] + sends[s][o][1]] for s in range(world)])
+        lo, hi = pd.leaf_range(o, world, P)
+        assert bool(((rr >= lo) & (rr < hi)).all())
+        torch.cuda.synchronize()
+        remote = pmk.DeviceQuery.from_items(models[o], rx.shape[0], rx.data_ptr(), rr.data_ptr())
+        remote.items(th)
+        ru = torch.empty(rx.shape[0], dtype=torch.float64, device="cuda")
+        rv = torch.empty(rx.shape[0], dtype=torch.float64, device="cuda")
+        remote.export_results(ru.data_ptr(), rv.data_ptr())
+        pmk.default_context().synchronize()
+        at = 0
+        for s in range(world):                            # what the second all-to-all delivers
+            s0, n0 = sends[s][o]
+            bufs[s][0][s0:s0 + n0] = ru[at:at + n0]
+            bufs[s][1][s0:s0 + n0] = rv[at:at + n0]
+            at += n0
     torch.cuda.synchronize()
     Y, V = np.empty(len(Xq)), np.empty(len(Xq))
     for r in range(world):
         q0, q1 = pd.query_range(r, world, len(Xq))
-        queries[r].mix(wth, q0, q1)
-        yr, vr = queries[r].fetch()
-        Y[q0:q1], V[q0:q1] = yr[q0:q1], vr[q0:q1]
+        queries[r].mix(wth)
+        Y[q0:q1], V[q0:q1] = queries[r].fetch()
     assert np.array_equal(Y, Y0) and np.array_equal(V, V0)
+    # a request for a leaf the model does not hold is refused
+    bad = np.array([0], dtype=np.int32)
+    with pytest.raises(pmk.PmkError):
+        pmk.DeviceQuery.from_items(models[1], 1, Xq[:1].ctypes.data, bad.ctypes.data)
+    empty = pmk.DeviceQuery.from_items(models[1], 0, None, None)
+    empty.items(th)
+    empty.export_results(None, None)
 
 
 def test_empty_and_tiny_queries():
