@@ -85,6 +85,9 @@ int  pmk_ctx_timer_ms(pmk_ctx *ctx, const char *stage, double *ms);
  * splitpoints :64-83, createchildren :166-217, labelleafnodes :131-159).
  * sign_mode +1: v = +z/|z| ; -1: v = -sign(z1) z/|z|  (SVD sign convention) */
 int     pmk_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, pmk_bsp **out);
+/* the same build on the GPU (X: host or device pointer, point-major N x D; N < 2^31): level-by-level segmented
+ * pairwise sums, radix-sort medians and stable splits; every output equals pmk_bsp_build's bit for bit.  Blocks. */
+int     pmk_bsp_build_device(pmk_ctx *ctx, int D, int64_t N, const double *X, int levels, int sign_mode, pmk_bsp **out);
 /* rebuild a tree from its pre-order hyperplanes (for shipping a tree between processes) */
 int     pmk_bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, pmk_bsp **out);
 void    pmk_bsp_destroy(pmk_bsp *bsp);

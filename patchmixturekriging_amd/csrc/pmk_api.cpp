@@ -22,6 +22,7 @@ void set_error(const char *fmt, ...)
 
 int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t);
 int bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, BspArrays &t);
+int bsp_build_device(pmk_ctx *c, int D, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t);
 int64_t bsp_find(const BspArrays &t, const double *x);
 int bsp_assign(const BspArrays &t, int64_t N, const double *X, double eps, int64_t *offsets, int64_t *inds,
                int64_t *list_offsets, int64_t *lists);
@@ -219,6 +220,24 @@ int pmk_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, 
     pmk_bsp *b = new (std::nothrow) pmk_bsp();
     if (!b) { set_error("out of memory"); return -100; }
     int rc = bsp_build(D, N, X, levels, sign_mode, b->t);
+    if (rc) { delete b; return rc; }
+    *out = b;
+    return 0;
+}
+
+int pmk_bsp_build_device(pmk_ctx *ctx, int D, int64_t N, const double *X, int levels, int sign_mode, pmk_bsp **out)
+{
+    if (!out) { set_error("pmk_bsp_build_device: out is NULL"); return -6; }
+    *out = nullptr;
+    if (!ctx) { set_error("pmk_bsp_build_device: context is NULL"); return -1; }
+    if (D < 1 || D > MAX_D) { set_error("pmk_bsp_build_device: D=%d outside 1..%d", D, MAX_D); return -1; }
+    if (N < 1 || N >= 0x7fffffff || !X) { set_error("pmk_bsp_build_device: N must be in 1..2^31-2"); return -2; }
+    if (levels < 2 || levels > 31) { set_error("pmk_bsp_build_device: levels=%d must be in 2..31", levels); return -4; }
+    if ((N >> (levels - 1)) < 1) { set_error("pmk_bsp_build_device: N=%lld < 2^(levels-1)", (long long)N); return -4; }
+    PMK_HIP(hipSetDevice(ctx->device));
+    pmk_bsp *b = new (std::nothrow) pmk_bsp();
+    if (!b) { set_error("out of memory"); return -100; }
+    int rc = bsp_build_device(ctx, D, N, X, levels, sign_mode, b->t);
     if (rc) { delete b; return rc; }
     *out = b;
     return 0;

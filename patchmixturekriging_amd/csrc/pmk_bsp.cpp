@@ -45,6 +45,58 @@ static void pairwise_sum(int D, const double *X, const int64_t *idx, int64_t fir
     for (int d = 0; d < D; ++d) out[d] = out[d] + tmp[d];
 }
 
+// gethyperplane (partition.jl:89-94) from the node's coordinate sum: mu = sum / n, z = x1 - mu, v = +-z/|z|
+void bsp_direction(int D, const double *sum, int64_t n, const double *x1, int sign_mode, double *v)
+{
+    double z[MAX_D];
+    double s = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double mu = sum[d] / (double)n;
+        z[d] = x1[d] - mu;
+        s = (d == 0) ? z[d] * z[d] : s + z[d] * z[d];
+    }
+    const double nz = std::sqrt(s);
+    if (nz == 0.0) {
+        for (int d = 0; d < D; ++d) v[d] = (d == 0) ? 1.0 : 0.0;
+    } else {
+        double sg = 1.0;
+        if (sign_mode < 0) sg = (z[0] > 0.0) ? -1.0 : 1.0;
+        for (int d = 0; d < D; ++d) v[d] = sg * (z[d] / nz);
+    }
+}
+
+// the same pairwise recursion split in two for the device build: the sequential leaf blocks [first, last] in
+// visiting order (summed on the GPU, one thread per block) ...
+void bsp_pairwise_blocks(int64_t first, int64_t last, int64_t base, std::vector<int64_t> &blk_first,
+                         std::vector<int64_t> &blk_last)
+{
+    if (last - first < 1024) {
+        blk_first.push_back(base + first);
+        blk_last.push_back(base + last);
+        return;
+    }
+    const int64_t mid = first + ((last - first) >> 1);
+    bsp_pairwise_blocks(first, mid, base, blk_first, blk_last);
+    bsp_pairwise_blocks(mid + 1, last, base, blk_first, blk_last);
+}
+
+// ... and the combination of their partial sums in the recursion's order (host)
+void bsp_pairwise_combine(int D, int64_t first, int64_t last, const double *partials, int64_t &cursor, double *out)
+{
+    if (last - first < 1024) {
+        const double *p = partials + (cursor++) * D;
+        for (int d = 0; d < D; ++d) out[d] = p[d];
+        return;
+    }
+    const int64_t mid = first + ((last - first) >> 1);
+    double tmp[MAX_D];
+    bsp_pairwise_combine(D, first, mid, partials, cursor, out);
+    bsp_pairwise_combine(D, mid + 1, last, partials, cursor, tmp);
+    for (int d = 0; d < D; ++d) out[d] = out[d] + tmp[d];
+}
+
+void bsp_fill_preorder(BspArrays &t);
+
 // [Julia stdlib] Statistics.median!: middle order statistic, or a/2 + b/2 of the two middle ones
 static double median_inplace(std::vector<double> &v)
 {
@@ -57,7 +109,7 @@ static double median_inplace(std::vector<double> &v)
     return lo / 2.0 + hi / 2.0;
 }
 
-static void fill_preorder(BspArrays &t)
+void bsp_fill_preorder(BspArrays &t)
 {
     t.pre.clear();
     t.pre.reserve((size_t)(t.P - 1));
@@ -97,21 +149,10 @@ int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, BspA
                 return -3;
             }
             const int64_t *idx = perm.data() + b;
-            double mu[MAX_D], z[MAX_D];
+            double mu[MAX_D];
             pairwise_sum(D, X, idx, 0, n - 1, mu);                       // gethyperplane :89
-            for (int d = 0; d < D; ++d) mu[d] = mu[d] / (double)n;
-            const double *x1 = X + idx[0] * D;                           // :90 (first point of the node)
-            double s = 0.0;
-            for (int d = 0; d < D; ++d) { z[d] = x1[d] - mu[d]; s = (d == 0) ? z[d] * z[d] : s + z[d] * z[d]; }
-            const double nz = std::sqrt(s);
             double *v = t.v.data() + (heap0 + nd) * D;
-            if (nz == 0.0) {
-                for (int d = 0; d < D; ++d) v[d] = (d == 0) ? 1.0 : 0.0;
-            } else {
-                double sg = 1.0;
-                if (sign_mode < 0) sg = (z[0] > 0.0) ? -1.0 : 1.0;
-                for (int d = 0; d < D; ++d) v[d] = sg * (z[d] / nz);    // :92-94
-            }
+            bsp_direction(D, mu, n, X + idx[0] * D, sign_mode, v);      // :89-94 (x1 = first point of the node)
             ev.resize((size_t)n);
             for (int64_t i = 0; i < n; ++i) ev[(size_t)i] = dot_seq(D, v, X + idx[i] * D);   // splitpoints :69
             evs = ev;
@@ -132,7 +173,7 @@ int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, BspA
     }
     t.leaf_off.assign(seg_off.begin(), seg_off.end());
     t.leaf_inds.assign(perm.begin(), perm.end());
-    fill_preorder(t);
+    bsp_fill_preorder(t);
     return 0;
 }
 
@@ -142,7 +183,7 @@ int bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp
     t.P = (int64_t)1 << (levels - 1);
     t.v.assign((size_t)((t.P - 1) * D), 0.0);
     t.c.assign((size_t)(t.P - 1), 0.0);
-    fill_preorder(t);
+    bsp_fill_preorder(t);
     for (int64_t k = 0; k < t.P - 1; ++k) {
         const int64_t h = t.pre[(size_t)k];
         for (int d = 0; d < D; ++d) t.v[(size_t)(h * D + d)] = hp_v[k * D + d];

@@ -95,13 +95,21 @@ def _native(root):
     return nat
 
 
-def setuppartition(X, level, sign_mode=1):
-    """setuppartition(X, level) -> root, X_parts, X_parts_inds   (partition.jl:106-129)"""
+def setuppartition(X, level, sign_mode=1, device=False, ctx=None):
+    """setuppartition(X, level) -> root, X_parts, X_parts_inds   (partition.jl:106-129)
+
+    device=True builds the tree on the GPU (pmk_bsp_build_device: same result bit for bit, for point sets where the
+    host build is the bottleneck)"""
     X = as_points(X)
     N, D = X.shape
     L = _lib.lib()
     h = C.c_void_p()
-    _lib.check(L.pmk_bsp_build(D, N, _d(X), int(level), sign_mode, C.byref(h)), "setuppartition")
+    if device:
+        from .context import default_context
+        ctx = ctx or default_context()
+        _lib.check(L.pmk_bsp_build_device(ctx.h, D, N, X.ctypes.data, int(level), sign_mode, C.byref(h)), "setuppartition")
+    else:
+        _lib.check(L.pmk_bsp_build(D, N, _d(X), int(level), sign_mode, C.byref(h)), "setuppartition")
     nat = _NativeTree(h)
     P = L.pmk_bsp_num_leaves(h)
     hp_v = np.empty((P - 1, D))

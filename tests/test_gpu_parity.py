@@ -644,3 +644,46 @@ def test_config_A_ibb1d_n512():
     pmk.query_(yq, xq[:, None], eta)
     assert np.abs(yq - O.query_rkhs(oth, x[:, None], oc, xq[:, None])).max() < 1e-7
     assert yq[0] == 0.0
+
+
+# ------------------------------------------------------------------------------------ device BSP build
+@pytest.mark.parametrize("D,N,levels,seed", [(1, 700, 4, 0), (2, 16000, 5, 25), (2, 4099, 3, 1), (3, 50001, 6, 2),
+                                             (4, 9000, 4, 3), (2, 300000, 9, 4), (2, 2051, 2, 5)])
+def test_device_bsp_build_is_bit_identical_to_host(D, N, levels, seed):
+    """pmk_bsp_build_device against the host build (itself pinned by tests/golden/bsp_*.npz and the oracle):
+    hyperplanes, offsets and every leaf's index list must be identical -- node sizes above and below the 1024-point
+    pairwise-summation block, odd counts, all supported dimensions."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.uniform(-5, 5, (N, D)) * np.array([1.0, 2.0, 0.5, 3.0][:D])
+    for sign_mode in (1, -1):
+        rh, Ph, Ih = pmk.setuppartition(X, levels, sign_mode=sign_mode)
+        rd, Pd, Id = pmk.setuppartition(X, levels, sign_mode=sign_mode, device=True)
+        hh, hd = pmk.fetchhyperplanes(rh), pmk.fetchhyperplanes(rd)
+        assert len(hh) == len(hd) == 2 ** (levels - 1) - 1
+        for a, b in zip(hh, hd):
+            assert np.array_equal(np.asarray(a.v), np.asarray(b.v)) and a.c == b.c
+        assert len(Ih) == len(Id)
+        for a, b in zip(Ih, Id):
+            assert np.array_equal(a, b)
+
+
+def test_device_bsp_build_duplicates_and_golden(golden):
+    """ties at the median (duplicated points), and the committed golden tree"""
+    rng = np.random.Generator(np.random.PCG64(9))
+    base = rng.uniform(-1, 1, (500, 2))
+    X = np.concatenate([base, base, base[:137]])            # exact duplicates -> equal projections
+    rh, _, Ih = pmk.setuppartition(X, 4)
+    rd, _, Id = pmk.setuppartition(X, 4, device=True)
+    for a, b in zip(pmk.fetchhyperplanes(rh), pmk.fetchhyperplanes(rd)):
+        assert np.array_equal(np.asarray(a.v), np.asarray(b.v)) and a.c == b.c
+    for a, b in zip(Ih, Id):
+        assert np.array_equal(a, b)
+    for name in ("bsp_2d.npz", "bsp_3d.npz"):
+        g = golden(name)
+        root, _, inds = pmk.setuppartition(g["X"], int(g["levels"]), device=True)
+        hv, hc = pmk.partition.hyperplane_arrays(root)
+        assert np.array_equal(hv, g["hp_v"]) and np.array_equal(hc, g["hp_c"])
+        assert np.array_equal(np.concatenate(inds), g["leaf_inds"])
+        assert np.array_equal(np.cumsum([0] + [len(i) for i in inds]), g["leaf_off"])
+    with pytest.raises(pmk.PmkError):
+        pmk.setuppartition(np.zeros((3, 2)), 4, device=True)
