@@ -106,6 +106,9 @@ int     pmk_bsp_arrays(const pmk_bsp *bsp, double *hp_v, double *hp_c,
  * (call once with NULLs to size the buffers). */
 int     pmk_bsp_assign(const pmk_bsp *bsp, int64_t N, const double *X, double eps,
                        int64_t *offsets, int64_t *inds, int64_t *list_offsets, int64_t *lists);
+/* the same assignment on the GPU (X: host or device pointer; outputs on the host, identical to pmk_bsp_assign's) */
+int     pmk_bsp_assign_device(pmk_ctx *ctx, const pmk_bsp *bsp, int64_t N, const double *X, double eps,
+                              int64_t *offsets, int64_t *inds, int64_t *list_offsets, int64_t *lists);
 /* findpartition(x, root, levels)  partition.jl:248-262 ; returns the leaf or <0 */
 int64_t pmk_bsp_findpartition(const pmk_bsp *bsp, const double *x);
 /* findneighbourpartitions(p, radius, root, levels, hps, home; delta)  mixtureGP.jl:339-405.

@@ -65,6 +65,7 @@ SIGNATURES = {
     "pmk_bsp_num_points": (C.c_int64, [_vp]),
     "pmk_bsp_arrays": (C.c_int, [_vp, _dp, _dp, _ip, _ip]),
     "pmk_bsp_assign": (C.c_int, [_vp, C.c_int64, _dp, C.c_double, _ip, _ip, _ip, _ip]),
+    "pmk_bsp_assign_device": (C.c_int, [_vp, _vp, C.c_int64, C.c_void_p, C.c_double, _ip, _ip, _ip, _ip]),
     "pmk_bsp_findpartition": (C.c_int64, [_vp, _dp]),
     "pmk_bsp_neighbours": (C.c_int64, [_vp, _dp, C.c_double, C.c_double, C.c_int64, _ip, _dp, _dp, _bp]),
     "pmk_kernel_matrix": (C.c_int, [_vp, _kp, C.c_int, C.c_int64, _dp, C.c_int64, _dp, _dp, C.c_int64]),

@@ -23,6 +23,8 @@ void set_error(const char *fmt, ...)
 int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t);
 int bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, BspArrays &t);
 int bsp_build_device(pmk_ctx *c, int D, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t);
+int bsp_assign_device(pmk_ctx *c, const BspArrays &t, int64_t N, const double *X, double eps, int64_t *offsets,
+                      int64_t *inds, int64_t *list_offsets, int64_t *lists);
 int64_t bsp_find(const BspArrays &t, const double *x);
 int bsp_assign(const BspArrays &t, int64_t N, const double *X, double eps, int64_t *offsets, int64_t *inds,
                int64_t *list_offsets, int64_t *lists);
@@ -280,6 +282,15 @@ int pmk_bsp_assign(const pmk_bsp *bsp, int64_t N, const double *X, double eps, i
 {
     if (!bsp || !offsets || (N > 0 && !X)) { set_error("pmk_bsp_assign: NULL argument"); return -1; }
     return bsp_assign(bsp->t, N, X, eps, offsets, inds, list_offsets, lists);
+}
+
+int pmk_bsp_assign_device(pmk_ctx *ctx, const pmk_bsp *bsp, int64_t N, const double *X, double eps, int64_t *offsets,
+                          int64_t *inds, int64_t *list_offsets, int64_t *lists)
+{
+    if (!ctx || !bsp || !offsets || (N > 0 && !X)) { set_error("pmk_bsp_assign_device: NULL argument"); return -1; }
+    if (N < 0 || N >= 0x7fffffff) { set_error("pmk_bsp_assign_device: N must be below 2^31-1"); return -2; }
+    PMK_HIP(hipSetDevice(ctx->device));
+    return bsp_assign_device(ctx, bsp->t, N, X, eps, offsets, inds, list_offsets, lists);
 }
 
 int64_t pmk_bsp_findpartition(const pmk_bsp *bsp, const double *x)

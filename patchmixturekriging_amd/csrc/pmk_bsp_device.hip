@@ -258,7 +258,134 @@ int build_levels(pmk_ctx *c, int64_t N, const double *X, int levels, int sign_mo
     return 0;
 }
 
+// find-eps-partitions (partition.jl:269-298) for every point: depth-first, left before right, so a point's leaves
+// come out in ascending order.  FILL = false counts (per point and per leaf), FILL = true writes the lists.
+template <int D, bool FILL>
+__global__ void eps_walk_kernel(int64_t N, const double *__restrict__ X, const double *__restrict__ v,
+                                const double *__restrict__ c, int64_t P, double eps, int32_t *__restrict__ cnt,
+                                unsigned long long *__restrict__ leaf_cnt, const int64_t *__restrict__ loff,
+                                int32_t *__restrict__ lists, int32_t *__restrict__ pair_point)
+{
+#pragma clang fp contract(off)
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    double x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = X[n * D + d];
+    const int64_t first_leaf = P - 1;
+    int64_t stack[34];
+    int sp = 0;
+    stack[sp++] = 0;
+    int32_t found = 0;
+    const int64_t base = FILL ? loff[n] : 0;
+    while (sp > 0) {
+        const int64_t node = stack[--sp];
+        if (node >= first_leaf) {
+            const int64_t leaf = node - first_leaf;
+            if (FILL) {
+                lists[base + found] = (int32_t)leaf;
+                pair_point[base + found] = (int32_t)n;
+            } else {
+                atomicAdd(leaf_cnt + leaf, 1ULL);
+            }
+            ++found;
+            continue;
+        }
+        const double *u = v + node * D;
+        double e = u[0] * x[0];
+#pragma unroll
+        for (int d = 1; d < D; ++d) e = e + u[d] * x[d];
+        const double cc = c[node];
+        if (e > cc - eps) stack[sp++] = 2 * node + 2;     // popped second
+        if (e < cc + eps) stack[sp++] = 2 * node + 1;     // popped first
+    }
+    if (!FILL) cnt[n] = found;
+}
+
+template <int D>
+int assign_levels(pmk_ctx *c, const BspArrays &t, int64_t N, const double *X, double eps, int64_t *offsets, int64_t *inds,
+                  int64_t *list_offsets, int64_t *lists)
+{
+    hipStream_t s = c->stream;
+    const int64_t P = t.P;
+    DevBuf mem;
+    double *dX = mem.get<double>((size_t)(N * D));
+    double *d_v = mem.get<double>((size_t)((P - 1) * D)), *d_c = mem.get<double>((size_t)(P - 1));
+    int32_t *cnt = mem.get<int32_t>((size_t)N + 1);
+    int64_t *loff = mem.get<int64_t>((size_t)N + 1);
+    unsigned long long *leaf_cnt = mem.get<unsigned long long>((size_t)P);
+    if (!dX || !d_v || !d_c || !cnt || !loff || !leaf_cnt) { set_error("pmk_bsp_assign_device: out of device memory"); return -100; }
+    PMK_HIP(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)(N * D), hipMemcpyDefault, s));
+    PMK_HIP(hipMemcpyAsync(d_v, t.v.data(), sizeof(double) * t.v.size(), hipMemcpyHostToDevice, s));
+    PMK_HIP(hipMemcpyAsync(d_c, t.c.data(), sizeof(double) * t.c.size(), hipMemcpyHostToDevice, s));
+    PMK_HIP(hipMemsetAsync(leaf_cnt, 0, sizeof(unsigned long long) * (size_t)P, s));
+    PMK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(N + 1), s));
+    hipLaunchKernelGGL((eps_walk_kernel<D, false>), dim3(blocks_for(N, 256)), dim3(256), 0, s, N, dX, d_v, d_c, P, eps, cnt,
+                       leaf_cnt, nullptr, nullptr, nullptr);
+    std::vector<unsigned long long> hcnt((size_t)P);
+    PMK_HIP(hipMemcpyAsync(hcnt.data(), leaf_cnt, sizeof(unsigned long long) * (size_t)P, hipMemcpyDeviceToHost, s));
+    PMK_HIP(hipStreamSynchronize(s));
+    offsets[0] = 0;
+    for (int64_t r = 0; r < P; ++r) offsets[r + 1] = offsets[r] + (int64_t)hcnt[(size_t)r];
+    if (!inds && !list_offsets && !lists) return 0;
+    const int64_t total = offsets[P];
+    if (total >= 0x7fffffff) { set_error("pmk_bsp_assign_device: too many (point, leaf) pairs"); return -5; }
+    // per-point offsets, then the lists and the (leaf, point) pairs in point order
+    size_t need_scan = 0, need_sort = 0;
+    int32_t *d_lists = mem.get<int32_t>((size_t)total), *d_pt = mem.get<int32_t>((size_t)total);
+    int32_t *d_keys = mem.get<int32_t>((size_t)total), *d_sorted_pt = mem.get<int32_t>((size_t)total);
+    int bits = 1;
+    while (((int64_t)1 << bits) < P) ++bits;
+    PMK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, cnt, loff, (int)(N + 1), s));
+    PMK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, d_lists, d_keys, d_pt, d_sorted_pt, (int)total, 0, bits, s));
+    const size_t tmp_bytes = std::max(need_scan, need_sort);
+    void *d_tmp = mem.get<char>(tmp_bytes);
+    if (!d_lists || !d_pt || !d_keys || !d_sorted_pt || !d_tmp) { set_error("pmk_bsp_assign_device: out of device memory"); return -100; }
+    size_t tb = tmp_bytes;
+    PMK_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, cnt, loff, (int)(N + 1), s));
+    hipLaunchKernelGGL((eps_walk_kernel<D, true>), dim3(blocks_for(N, 256)), dim3(256), 0, s, N, dX, d_v, d_c, P, eps, cnt,
+                       leaf_cnt, loff, d_lists, d_pt);
+    PMK_HIP(hipGetLastError());
+    std::vector<int32_t> h32((size_t)std::max<int64_t>(total, 1));
+    if (inds && total > 0) {
+        // stable sort by leaf: within a leaf the points stay in ascending order (X_set_inds, partition.jl:320-330)
+        tb = tmp_bytes;
+        PMK_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_lists, d_keys, d_pt, d_sorted_pt, (int)total, 0, bits, s));
+        PMK_HIP(hipMemcpyAsync(h32.data(), d_sorted_pt, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+        PMK_HIP(hipStreamSynchronize(s));
+        for (int64_t i = 0; i < total; ++i) inds[i] = h32[(size_t)i];
+    }
+    if (lists && total > 0) {
+        PMK_HIP(hipMemcpyAsync(h32.data(), d_lists, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+        PMK_HIP(hipStreamSynchronize(s));
+        for (int64_t i = 0; i < total; ++i) lists[i] = h32[(size_t)i];
+    }
+    if (list_offsets) {
+        PMK_HIP(hipMemcpyAsync(list_offsets, loff, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyDeviceToHost, s));
+        PMK_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
 }  // namespace
+
+// organizetrainingsets (partition.jl:301-357) on the GPU; same outputs as bsp_assign of pmk_bsp.cpp
+int bsp_assign_device(pmk_ctx *c, const BspArrays &t, int64_t N, const double *X, double eps, int64_t *offsets,
+                      int64_t *inds, int64_t *list_offsets, int64_t *lists)
+{
+    if (N == 0) {
+        for (int64_t r = 0; r <= t.P; ++r) offsets[r] = 0;
+        if (list_offsets) list_offsets[0] = 0;
+        return 0;
+    }
+    switch (t.D) {
+    case 1: return assign_levels<1>(c, t, N, X, eps, offsets, inds, list_offsets, lists);
+    case 2: return assign_levels<2>(c, t, N, X, eps, offsets, inds, list_offsets, lists);
+    case 3: return assign_levels<3>(c, t, N, X, eps, offsets, inds, list_offsets, lists);
+    case 4: return assign_levels<4>(c, t, N, X, eps, offsets, inds, list_offsets, lists);
+    default: set_error("pmk_bsp_assign_device: D=%d outside 1..%d", t.D, MAX_D); return -1;
+    }
+}
 
 int bsp_build_device(pmk_ctx *c, int D, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t)
 {

@@ -162,20 +162,29 @@ def findpartition(x, root, levels=None):
     return int(r)
 
 
-def organizetrainingsets(root, levels, X0, eps):
+def organizetrainingsets(root, levels, X0, eps, device=False, ctx=None):
     """organizetrainingsets(root, levels, X0, eps) -> X_set, X_set_inds, regions_list_set,
-    problematic_inds   (partition.jl:301-357)"""
+    problematic_inds   (partition.jl:301-357).  device=True runs the assignment on the GPU (same outputs)."""
     X0 = as_points(X0)
     N = X0.shape[0]
     L = _lib.lib()
     h = _native(root).h
     P = L.pmk_bsp_num_leaves(h)
     off = np.empty(P + 1, dtype=np.int64)
-    _lib.check(L.pmk_bsp_assign(h, N, _d(X0), float(eps), _i(off), None, None, None), "organizetrainingsets")
+    if device:
+        from .context import default_context
+        ctx = ctx or default_context()
+
+        def assign(*out):
+            return L.pmk_bsp_assign_device(ctx.h, h, N, X0.ctypes.data, float(eps), *out)
+    else:
+        def assign(*out):
+            return L.pmk_bsp_assign(h, N, _d(X0), float(eps), *out)
+    _lib.check(assign(_i(off), None, None, None), "organizetrainingsets")
     inds = np.empty(max(int(off[-1]), 1), dtype=np.int64)
     loff = np.empty(N + 1, dtype=np.int64)
     lists = np.empty(max(int(off[-1]), 1), dtype=np.int64)
-    _lib.check(L.pmk_bsp_assign(h, N, _d(X0), float(eps), _i(off), _i(inds), _i(loff), _i(lists)), "organizetrainingsets")
+    _lib.check(assign(_i(off), _i(inds), _i(loff), _i(lists)), "organizetrainingsets")
     X_set_inds = [inds[off[r]:off[r + 1]].copy() for r in range(P)]
     X_set = [X0[ix] for ix in X_set_inds]
     regions_list_set = [lists[loff[n]:loff[n + 1]].copy() for n in range(N)]

@@ -687,3 +687,22 @@ def test_device_bsp_build_duplicates_and_golden(golden):
         assert np.array_equal(np.cumsum([0] + [len(i) for i in inds]), g["leaf_off"])
     with pytest.raises(pmk.PmkError):
         pmk.setuppartition(np.zeros((3, 2)), 4, device=True)
+
+
+@pytest.mark.parametrize("D,N,levels,eps,seed", [(2, 16000, 5, 0.18, 25), (2, 16000, 5, 0.0, 25), (3, 30000, 6, 0.3, 2),
+                                                 (1, 900, 4, 0.05, 0), (2, 200000, 9, 0.044, 4)])
+def test_device_eps_assignment_is_identical_to_host(D, N, levels, eps, seed):
+    """pmk_bsp_assign_device against the host organizetrainingsets (pinned by the golden trees): X_set_inds in
+    ascending order per leaf, regions_list_set per point in visiting order, eps = 0 included."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    X = rng.uniform(-5, 5, (N, D)) * np.array([1.0, 2.0, 0.5, 3.0][:D])
+    root, _, _ = pmk.setuppartition(X, levels)
+    Xh, Ih, Lh, _ = pmk.organizetrainingsets(root, levels, X, eps)
+    Xd, Id, Ld, _ = pmk.organizetrainingsets(root, levels, X, eps, device=True)
+    assert len(Ih) == len(Id)
+    for a, b in zip(Ih, Id):
+        assert np.array_equal(a, b)
+    assert np.array_equal(np.concatenate(Lh), np.concatenate(Ld))
+    assert np.array_equal([len(l) for l in Lh], [len(l) for l in Ld])
+    for a, b in zip(Xh, Xd):
+        assert np.array_equal(a, b)
