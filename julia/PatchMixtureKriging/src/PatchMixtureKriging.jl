@@ -181,12 +181,19 @@ function buildnodes(h::Ptr{Cvoid}, D::Int, levels::Int, X)
     return make(nothing, 0), off, inds
 end
 
-"""setuppartition(X, level) -> root, X_parts, X_parts_inds (src/patchwork/partition.jl:106-129)"""
-function setuppartition(X::Vector{Vector{T}}, level; sign_mode::Int = 1) where T
+"""setuppartition(X, level) -> root, X_parts, X_parts_inds (src/patchwork/partition.jl:106-129);
+`device = true` builds the tree on the GPU (pmk_bsp_build_device, same result bit for bit)"""
+function setuppartition(X::Vector{Vector{T}}, level; sign_mode::Int = 1, device::Bool = false) where T
     Xm = pack(X); D, N = size(Xm)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:pmk_bsp_build, libpmk), Cint, (Cint, Int64, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
-        D, N, Xm, level, sign_mode, h), "setuppartition")
+    if device
+        check(ccall((:pmk_bsp_build_device, libpmk), Cint,
+            (Ptr{Cvoid}, Cint, Int64, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
+            context(), D, N, Xm, level, sign_mode, h), "setuppartition")
+    else
+        check(ccall((:pmk_bsp_build, libpmk), Cint, (Cint, Int64, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
+            D, N, Xm, level, sign_mode, h), "setuppartition")
+    end
     root, off, inds = buildnodes(h[], D, Int(level), X)
     NATIVE[root] = h[]
     finalizer(r -> (ccall((:pmk_bsp_destroy, libpmk), Cvoid, (Ptr{Cvoid},), pop!(NATIVE, r, C_NULL)); nothing), root)
@@ -200,16 +207,20 @@ end
 findpartition(x::Vector{T}, root, levels::Int) where T =
     Int(ccall((:pmk_bsp_findpartition, libpmk), Int64, (Ptr{Cvoid}, Ptr{Float64}), native(root), Vector{Float64}(x))) + 1
 
-"""organizetrainingsets(root, levels, X0, ε) (partition.jl:301-357)"""
-function organizetrainingsets(root, levels::Int, X0::Vector{Vector{T}}, ε::T) where T
+"""organizetrainingsets(root, levels, X0, ε) (partition.jl:301-357); `device = true`: pmk_bsp_assign_device"""
+function organizetrainingsets(root, levels::Int, X0::Vector{Vector{T}}, ε::T; device::Bool = false) where T
     Xm = pack(X0); D, N = size(Xm)
     h = native(root)
     P = Int(ccall((:pmk_bsp_num_leaves, libpmk), Int64, (Ptr{Cvoid},), h))
     off = Vector{Int64}(undef, P + 1)
     sig = (Ptr{Cvoid}, Int64, Ptr{Float64}, Float64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64})
-    check(ccall((:pmk_bsp_assign, libpmk), Cint, sig, h, N, Xm, ε, off, C_NULL, C_NULL, C_NULL), "organizetrainingsets")
+    dsig = (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Float64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64})
+    assign(o, i, lo, li) = device ?
+        ccall((:pmk_bsp_assign_device, libpmk), Cint, dsig, context(), h, N, Xm, ε, o, i, lo, li) :
+        ccall((:pmk_bsp_assign, libpmk), Cint, sig, h, N, Xm, ε, o, i, lo, li)
+    check(assign(off, C_NULL, C_NULL, C_NULL), "organizetrainingsets")
     inds = Vector{Int64}(undef, max(off[end], 1)); loff = Vector{Int64}(undef, N + 1); lists = similar(inds)
-    check(ccall((:pmk_bsp_assign, libpmk), Cint, sig, h, N, Xm, ε, off, inds, loff, lists), "organizetrainingsets")
+    check(assign(off, inds, loff, lists), "organizetrainingsets")
     X_set_inds = [Vector{Int}(inds[off[r]+1:off[r+1]] .+ 1) for r = 1:P]
     X_set = [X0[ix] for ix in X_set_inds]
     regions_list_set = [Vector{Int}(lists[loff[n]+1:loff[n+1]] .+ 1) for n = 1:N]
