@@ -105,23 +105,37 @@ __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, 
 constexpr int TRI_LDS_DOUBLES = 10 * 32 * 32;
 
 // cooperative copy by all `nthreads` threads of the workgroup; caller synchronises before and after.
-// L: factored diagonal tile (column-major, ldl); ninv: its 4 negated inverted diagonal blocks (global)
+// L: factored diagonal tile (column-major, ldl); ninv: its 4 negated inverted diagonal blocks (global).
+// The copy is written as batches of independent loads followed by their LDS stores: left as a rolled
+// load -> wait -> store loop (what hipcc makes of the obvious form) it is 20 serialised L2 round trips,
+// ~10 us at the head of every workgroup.
 __device__ __forceinline__ void stage_tri_operands(real *lds, const real *L, int64_t ldl, const real *ninv,
                                                    int tid, int nthreads)
 {
-    // 16-byte pieces: 512 per block
-    for (int e = tid; e < 10 * 512; e += nthreads) {
-        const int b = e >> 9, w = e & 511;          // block, piece
-        const int i = 2 * (w & 15), c = w >> 4;     // rows i, i+1 of column c
-        real2_t v;
-        if (b < 6) {
-            const int s = (b >= 3) ? 3 : (b >= 1 ? 2 : 1);
-            const int j = b - s * (s - 1) / 2;
-            v = *reinterpret_cast<const real2_t *>(L + 32 * s + i + (int64_t)(32 * j + c) * ldl);
-        } else {
-            v = *reinterpret_cast<const real2_t *>(ninv + 1024 * (b - 6) + i + 32 * c);
+    constexpr int PIECES = 10 * 512;            // 16-byte pieces: 512 per 32 x 32 block
+    constexpr int BATCH = 10;
+    for (int e0 = tid; e0 < PIECES; e0 += BATCH * nthreads) {
+        real2_t v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = e0 + u * nthreads;
+            const int ec = e < PIECES ? e : tid;        // clamp (only when PIECES is not a multiple of the batch)
+            const int b = ec >> 9, w = ec & 511;        // block, piece
+            const int i = 2 * (w & 15), c = w >> 4;     // rows i, i+1 of column c
+            const int sblk = (b >= 3) ? 3 : (b >= 1 ? 2 : 1);
+            const int j = b - sblk * (sblk - 1) / 2;
+            const real *src = (b < 6) ? L + 32 * sblk + i + (int64_t)(32 * j + c) * ldl : ninv + 1024 * (b - 6) + i + 32 * c;
+            v[u] = *reinterpret_cast<const real2_t *>(src);
         }
-        *reinterpret_cast<real2_t *>(lds + 1024 * b + i + 32 * c) = v;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = e0 + u * nthreads;
+            if (e < PIECES) {
+                const int b = e >> 9, w = e & 511;
+                const int i = 2 * (w & 15), c = w >> 4;
+                *reinterpret_cast<real2_t *>(lds + 1024 * b + i + 32 * c) = v[u];
+            }
+        }
     }
 }
 
