@@ -319,21 +319,18 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
         return;
     }
 
-    // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per
-    // workgroup; the loads are in flight while the GEMM below runs
+    // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per workgroup
     if ((int64_t)(k + 1 + bx) * TILE >= pd.ld) return;      // whole workgroup: ld is a multiple of TILE
     __shared__ real tri[TRI_LDS_DOUBLES];
-#ifndef PMK_PANEL_EXP
-#define PMK_PANEL_EXP 0
-#endif
-    if (!(PMK_PANEL_EXP & 2)) stage_tri_operands(tri, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
-    if (!(PMK_PANEL_EXP & (2 | 16))) __syncthreads();
     const int64_t r0 = (int64_t)(k + 1 + bx) * TILE + 32 * wave;
     real *out = S + r0 + 2 * (lane & 15) + c0 * ld;   // rows of this lane, first column of the block column
 
-    // acc starts as -A[rows, block column k]; the GEMM adds L[rows,0:k] L[k,0:k]^T, so acc = -T
+    // acc starts as -A[rows, block column k]; the GEMM adds L[rows,0:k] L[k,0:k]^T, so acc = -T.  The tile comes
+    // from HBM (first touch): its loads are issued before the operand staging so that the two latencies overlap
+    // instead of adding up.
     WaveTile<4, 1> acc;   // I = the 128 columns of block column k, J = 32 rows
     if (FUSE) {
+        stage_tri_operands(tri, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
         const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
         const int gr = (int)r0 + 2 * (lane & 15);
         real pr0[D], pr1[D];
@@ -348,8 +345,6 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
                 acc.f[fi][0][q] = -src.value(gr, pr0, gc, pc);
                 acc.f[fi][1][q] = -src.value(gr + 1, pr1, gc, pc);
             }
-    } else if (PMK_PANEL_EXP & 8) {
-        acc.zero();
     } else {
 #pragma unroll
         for (int fi = 0; fi < 8; ++fi)
@@ -357,18 +352,23 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
             for (int q = 0; q < 4; ++q) {
                 const int cl = tile_i(fi, lane, q);
                 const real2_t a = *reinterpret_cast<const real2_t *>(out + cl * ld);
-                acc.f[fi][0][q] = -a[0];
-                acc.f[fi][1][q] = -a[1];
+                acc.f[fi][0][q] = a[0];
+                acc.f[fi][1][q] = a[1];
+            }
+        __builtin_amdgcn_sched_barrier(0);      // keep the tile loads ahead of the staging loads
+        stage_tri_operands(tri, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc.f[fi][0][q] = -acc.f[fi][0][q];
+                acc.f[fi][1][q] = -acc.f[fi][1][q];
             }
     }
+    __syncthreads();
     if (k > 0) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
-    if (PMK_PANEL_EXP & 16) __syncthreads();
     // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
-    if (!(PMK_PANEL_EXP & 1)) tri_solve_inplace<1>(acc, tri, lane);
-    if (PMK_PANEL_EXP & 4) {
-        if (acc.f[0][0][0] == (real)1.2345e-300) out[0] = acc.f[7][1][3];     // keep the computation alive
-        return;
-    }
+    tri_solve_inplace<1>(acc, tri, lane);
 #pragma unroll
     for (int fi = 0; fi < 8; ++fi)
 #pragma unroll

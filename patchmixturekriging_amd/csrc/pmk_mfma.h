@@ -109,11 +109,11 @@ constexpr int TRI_LDS_DOUBLES = 10 * 32 * 32;
 // The copy is written as batches of independent loads followed by their LDS stores: left as a rolled
 // load -> wait -> store loop (what hipcc makes of the obvious form) it is 20 serialised L2 round trips,
 // ~10 us at the head of every workgroup.
+template <int BATCH = 10>
 __device__ __forceinline__ void stage_tri_operands(real *lds, const real *L, int64_t ldl, const real *ninv,
                                                    int tid, int nthreads)
 {
     constexpr int PIECES = 10 * 512;            // 16-byte pieces: 512 per 32 x 32 block
-    constexpr int BATCH = 10;
     for (int e0 = tid; e0 < PIECES; e0 += BATCH * nthreads) {
         real2_t v[BATCH];
 #pragma unroll
