@@ -90,8 +90,30 @@ __global__ __launch_bounds__(256, 2) void chol_diag_kernel(const PatchDesc *__re
     // ---- A[kk] -= L[k,k-1] L[k,k-1]^T in place in the slab (older block columns were applied by the look-ahead
     //      workgroup of the previous panel launch); lower 64 x 64 sub-tiles only
     if (!(h == 0 && g == 1) && ((k > 0 && !(skip & 16)) || (FUSE && k == 0))) {
+        // acc starts as -A[kk] (all of the sub-tile's loads in flight at once; read-modify-write per element made
+        // hipcc serialise 16 L2 round trips behind the GEMM), the GEMM adds L L^T, the store negates
         WaveTile<2, 2> acc;
-        acc.zero();
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int pj = 0; pj < 2; ++pj) {
+                    const int cl = 64 * g + tile_i(fi, lane, q);
+                    const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
+                    real2_t a;
+                    if (FUSE && k == 0) {          // first tile: nothing was written to the slab, evaluate K here
+                        const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
+                        real pc[D], pr0[D], pr1[D];
+                        src.point(cl, pc); src.point(rl, pr0); src.point(rl + 1, pr1);
+                        a[0] = src.value(rl, pr0, cl, pc);
+                        a[1] = src.value(rl + 1, pr1, cl, pc);
+                    } else {
+                        a = *reinterpret_cast<const real2_t *>(Akk + rl + (int64_t)cl * ld);
+                    }
+                    acc.f[fi][2 * pj][q] = -a[0];
+                    acc.f[fi][2 * pj + 1][q] = -a[1];
+                }
         if (k > 0) {
             const real *Lk = S + d0 + (d0 - TILE) * ld;      // L[k, k-1]: 128 x 128
             gemm_nt<2, 2, PF_DIAG>(acc, Lk + 64 * g, ld, Lk + 64 * h, ld, TILE, lane);
@@ -104,20 +126,10 @@ __global__ __launch_bounds__(256, 2) void chol_diag_kernel(const PatchDesc *__re
                 for (int pj = 0; pj < 2; ++pj) {
                     const int cl = 64 * g + tile_i(fi, lane, q);
                     const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
-                    real2_t *p = reinterpret_cast<real2_t *>(Akk + rl + (int64_t)cl * ld);
                     real2_t a;
-                    if (FUSE && k == 0) {          // first tile: nothing was written to the slab, evaluate K here
-                        const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
-                        real pc[D], pr0[D], pr1[D];
-                        src.point(cl, pc); src.point(rl, pr0); src.point(rl + 1, pr1);
-                        a[0] = src.value(rl, pr0, cl, pc);
-                        a[1] = src.value(rl + 1, pr1, cl, pc);
-                    } else {
-                        a = *p;
-                    }
-                    a[0] -= acc.f[fi][2 * pj][q];
-                    a[1] -= acc.f[fi][2 * pj + 1][q];
-                    *p = a;
+                    a[0] = -acc.f[fi][2 * pj][q];
+                    a[1] = -acc.f[fi][2 * pj + 1][q];
+                    *reinterpret_cast<real2_t *>(Akk + rl + (int64_t)cl * ld) = a;
                 }
     }
     // ---- forward-solve right-hand side: y_k - L[k,0:k-1] z (look-ahead) - L[k,k-1] z_{k-1}
@@ -127,7 +139,13 @@ __global__ __launch_bounds__(256, 2) void chol_diag_kernel(const PatchDesc *__re
         if (k > 0) {
             const real *Lr = S + d0 + row + (d0 - TILE + 64 * half) * ld;
             const real *zz = z + pd.yoff + d0 - TILE + 64 * half;
-            for (int c = 0; c < 64; ++c) s += Lr[(int64_t)c * ld] * zz[c];
+            for (int cb = 0; cb < 64; cb += 16) {          // 16 independent column loads in flight per batch
+                real lv[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) lv[c] = Lr[(int64_t)(cb + c) * ld];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) s += lv[c] * zz[cb + c];
+            }
         }
         rhs[tid] = s;
     }
@@ -271,9 +289,8 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
         if (k + 1 >= pd.nt) return;
         const int h = wave >> 1, g = wave & 1;
         if ((k > 0 || FUSE) && !(h == 0 && g == 1)) {
+            // acc = -A[k+1,k+1] (or -K evaluated) up-front, GEMM adds L L^T, the store negates (see diag_kernel)
             WaveTile<2, 2> acc;
-            acc.zero();
-            if (k > 0) gemm_nt<2, 2, PF_DIAG>(acc, S + t0 + 64 * g, ld, S + t0 + 64 * h, ld, k * TILE, lane);
             real *Att = S + t0 + t0 * ld;
             const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
 #pragma unroll
@@ -284,7 +301,6 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
                     for (int pj = 0; pj < 2; ++pj) {
                         const int cl = 64 * g + tile_i(fi, lane, q);
                         const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
-                        real2_t *p = reinterpret_cast<real2_t *>(Att + rl + (int64_t)cl * ld);
                         real2_t a;
                         if (FUSE) {
                             real pc[D], pr0[D], pr1[D];
@@ -293,11 +309,24 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
                             a[0] = src.value(gr, pr0, gc, pc);
                             a[1] = src.value(gr + 1, pr1, gc, pc);
                         } else {
-                            a = *p;
+                            a = *reinterpret_cast<const real2_t *>(Att + rl + (int64_t)cl * ld);
                         }
-                        a[0] -= acc.f[fi][2 * pj][q];
-                        a[1] -= acc.f[fi][2 * pj + 1][q];
-                        *p = a;
+                        acc.f[fi][2 * pj][q] = -a[0];
+                        acc.f[fi][2 * pj + 1][q] = -a[1];
+                    }
+            if (k > 0) gemm_nt<2, 2, PF_DIAG>(acc, S + t0 + 64 * g, ld, S + t0 + 64 * h, ld, k * TILE, lane);
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int pj = 0; pj < 2; ++pj) {
+                        const int cl = 64 * g + tile_i(fi, lane, q);
+                        const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
+                        real2_t a;
+                        a[0] = -acc.f[fi][2 * pj][q];
+                        a[1] = -acc.f[fi][2 * pj + 1][q];
+                        *reinterpret_cast<real2_t *>(Att + rl + (int64_t)cl * ld) = a;
                     }
         }
         if (h == 0 && g == 1) {
@@ -305,12 +334,15 @@ __global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__r
             const real *Lr = S + t0 + 2 * lane;
             const real *zz = z + pd.yoff;
             real2_t s0 = {0.0, 0.0}, s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, s3 = {0.0, 0.0};
-            for (int c = 0; c < k * TILE; c += 4) {
-                const real2_t a0 = *reinterpret_cast<const real2_t *>(Lr + (int64_t)c * ld);
-                const real2_t a1 = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + 1) * ld);
-                const real2_t a2 = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + 2) * ld);
-                const real2_t a3 = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + 3) * ld);
-                s0 += a0 * zz[c]; s1 += a1 * zz[c + 1]; s2 += a2 * zz[c + 2]; s3 += a3 * zz[c + 3];
+            for (int c = 0; c < k * TILE; c += 16) {     // 16 independent column loads in flight per batch
+                real2_t av[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) av[u] = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + u) * ld);
+#pragma unroll
+                for (int u = 0; u < 16; u += 4) {
+                    s0 += av[u] * zz[c + u]; s1 += av[u + 1] * zz[c + u + 1];
+                    s2 += av[u + 2] * zz[c + u + 2]; s3 += av[u + 3] * zz[c + u + 3];
+                }
             }
             const real2_t sum = (s0 + s1) + (s2 + s3);
             const real2_t yy = *reinterpret_cast<const real2_t *>(y + pd.yoff + t0 + 2 * lane);
