@@ -440,16 +440,31 @@ __global__ __launch_bounds__(1024) void chol_backsolve_kernel(const PatchDesc *_
         const int64_t d0 = (int64_t)k * TILE;
         // stage L[kk] and its -D^-1 blocks (coalesced), overlapping with the column dots below
         {
+            // all ten loads of a thread in flight before the first LDS store (a rolled load -> store loop is one
+            // L2 round trip per piece)
             const real *Lkk = S + d0 + d0 * ld;
-            for (int e = tid; e < 6 * SB * SB; e += 1024) {
+            const real *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
+            real lv[6], nv[4];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int e = tid + 1024 * u;
                 const int b = e >> 10, i = e & 31, c = (e >> 5) & 31;
                 const int bi = (b >= 3) ? 3 : (b >= 1 ? 2 : 1), bs = b - bi * (bi - 1) / 2;   // block (bi, bs), bi > bs
-                Lt[b * (SB * LDN) + i + c * LDN] = Lkk[SB * bi + i + (int64_t)(SB * bs + c) * ld];
+                lv[u] = Lkk[SB * bi + i + (int64_t)(SB * bs + c) * ld];
             }
-            const real *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB);
-            for (int e = tid; e < 4 * SB * SB; e += 1024) {
-                const int s = e >> 10, i = e & 31, c = (e >> 5) & 31;
-                Nt[s * (SB * LDN) + i + c * LDN] = Ni[e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nv[u] = Ni[tid + 1024 * u];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int e = tid + 1024 * u;
+                const int b = e >> 10, i = e & 31, c = (e >> 5) & 31;
+                Lt[b * (SB * LDN) + i + c * LDN] = lv[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + 1024 * u;
+                const int sb = e >> 10, i = e & 31, c = (e >> 5) & 31;
+                Nt[sb * (SB * LDN) + i + c * LDN] = nv[u];
             }
         }
         // r[col] = z_k[col] - sum_{i >= d0 + TILE} L[i, d0 + col] c[i]: one wave per column, coalesced rows
