@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
                         real2_t o;
                         o[0] = acc.f[fi][0][qq];
                         o[1] = acc.f[fi][1][qq];
-                        *reinterpret_cast<real2_t *>(V + (int64_t)row * TQ + 2 * (lane & 15)) = o;
+                        __builtin_nontemporal_store(o, reinterpret_cast<real2_t *>(V + (int64_t)row * TQ + 2 * (lane & 15)));
                     }
             }
         }
