@@ -59,6 +59,18 @@ static void dev_free(T *&p)
     p = nullptr;
 }
 
+// device temporary of a blocking host-API call: released on every return path
+template <typename T>
+struct DevTmp {
+    T *p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() { if (p) (void)hipFree((void *)p); }
+    int alloc(int64_t count) { return dev_alloc(&p, count); }
+    operator T *() const { return p; }
+};
+
 // host double buffer -> device buffer of the model's element type (and back)
 static int upload_real(const pmk_model *m, void *dst, int64_t elem_off, const double *src, size_t count)
 {
@@ -143,10 +155,20 @@ int pmk_ctx_create(int device, pmk_ctx **out)
     pmk_ctx *c = new (std::nothrow) pmk_ctx();
     if (!c) { set_error("out of memory"); return -100; }
     c->device = device;
-    PMK_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("pmk_ctx_create: device %d: %s", device, hipGetErrorString(hipGetLastError()));
+        delete c;
+        return -100;
+    }
+    c->num_cu = prop.multiProcessorCount;
     c->stream = c->own_stream;
-    if (const char *e = getenv("PMK_FIT_GROUPS")) c->fit_groups = std::max(1, atoi(e));
-    if (const char *e = getenv("PMK_FUSE_K1")) c->fuse_k1 = atoi(e) != 0;
+    // kernel attributes are per device: set them for this context's device (current after hipSetDevice above)
+    if (pmk::f64::set_device_attributes() || pmk::f32::set_device_attributes() || pmk::set_plan_attributes()) {
+        pmk_ctx_destroy(c);
+        return -100;
+    }
     *out = c;
     return 0;
 }
@@ -170,9 +192,6 @@ void pmk_ctx_destroy(pmk_ctx *ctx)
     if (!ctx) return;
     for (auto &t : ctx->tm) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto &e : ctx->panel_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    for (auto &st : ctx->aux) (void)hipStreamDestroy(st);
-    for (auto &ev : ctx->aux_done) (void)hipEventDestroy(ev);
-    if (ctx->fork) (void)hipEventDestroy(ctx->fork);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -320,23 +339,22 @@ int pmk_kernel_matrix(pmk_ctx *ctx, const pmk_kernel_desc *th, int D, int64_t n,
     PMK_HIP(hipSetDevice(ctx->device));
     std::vector<double> hx((size_t)(n * D)), hz;
     pack_soa(D, n, n, X, hx.data());
-    double *dx = nullptr, *dz = nullptr, *dK = nullptr;
-    if (dev_alloc(&dx, n * D)) return -100;
+    DevTmp<double> dx, dz, dK;
+    if (dx.alloc(n * D)) return -100;
     PMK_HIP(hipMemcpyAsync(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, ctx->stream));
     if (!sym) {
         hz.resize((size_t)(mc * D));
         pack_soa(D, mc, mc, Z, hz.data());
-        if (dev_alloc(&dz, mc * D)) return -100;
+        if (dz.alloc(mc * D)) return -100;
         PMK_HIP(hipMemcpyAsync(dz, hz.data(), sizeof(double) * hz.size(), hipMemcpyHostToDevice, ctx->stream));
     }
-    if (dev_alloc(&dK, n * mc)) return -100;
+    if (dK.alloc(n * mc)) return -100;
     int rc = launch_kernel_matrix_dense(*th, D, n, dx, n, mc, sym ? dx : dz, sym ? n : mc, dK, n, sym, ctx->stream);
     if (!rc) {
         PMK_HIP(hipMemcpy2DAsync(K, sizeof(double) * ldk, dK, sizeof(double) * n, sizeof(double) * n, (size_t)mc,
                                  hipMemcpyDeviceToHost, ctx->stream));
-        PMK_HIP(hipStreamSynchronize(ctx->stream));
     }
-    dev_free(dx); dev_free(dz); dev_free(dK);
+    PMK_HIP(hipStreamSynchronize(ctx->stream));     // also on failure: the temporaries must outlive the queued copies
     return rc;
 }
 
@@ -351,17 +369,14 @@ int pmk_query_mean(pmk_ctx *ctx, const pmk_kernel_desc *th, int D, int64_t n, co
     PMK_HIP(hipSetDevice(ctx->device));
     std::vector<double> hx((size_t)(n * D));
     pack_soa(D, n, n, X, hx.data());
-    double *dx = nullptr, *dc = nullptr, *dq = nullptr, *dy = nullptr;
-    if (dev_alloc(&dx, n * D) || dev_alloc(&dc, n) || dev_alloc(&dq, Nq * D) || dev_alloc(&dy, Nq)) return -100;
+    DevTmp<double> dx, dc, dq, dy;
+    if (dx.alloc(n * D) || dc.alloc(n) || dq.alloc(Nq * D) || dy.alloc(Nq)) return -100;
     PMK_HIP(hipMemcpyAsync(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, ctx->stream));
     PMK_HIP(hipMemcpyAsync(dc, c, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     PMK_HIP(hipMemcpyAsync(dq, Xq, sizeof(double) * Nq * D, hipMemcpyHostToDevice, ctx->stream));
     int rc = launch_query_mean(*th, D, n, dx, n, dc, Nq, dq, dy, ctx->stream);
-    if (!rc) {
-        PMK_HIP(hipMemcpyAsync(Yq, dy, sizeof(double) * Nq, hipMemcpyDeviceToHost, ctx->stream));
-        PMK_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    dev_free(dx); dev_free(dc); dev_free(dq); dev_free(dy);
+    if (!rc) PMK_HIP(hipMemcpyAsync(Yq, dy, sizeof(double) * Nq, hipMemcpyDeviceToHost, ctx->stream));
+    PMK_HIP(hipStreamSynchronize(ctx->stream));
     return rc;
 }
 
@@ -370,6 +385,7 @@ void pmk_model_destroy(pmk_model *m)
 {
     if (!m) return;
     dev_free(m->d_desc); dev_free(m->d_info); dev_free(m->d_hv); dev_free(m->d_hc); dev_free(m->d_pre);
+    dev_free(m->d_order);
     for (void **p : {&m->d_x, &m->d_y, &m->d_z, &m->d_c, &m->d_a, &m->d_inv, &m->d_strip}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -442,7 +458,23 @@ int pmk_model_create_ex(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const 
     rc |= alloc_real(&m->d_a, a);
     rc |= alloc_real(&m->d_inv, io);
     rc |= dev_alloc(&m->d_info, P);
+    rc |= dev_alloc(&m->d_order, P);
     if (rc) { pmk_model_destroy(m); return -100; }
+    {
+        // factorisation order: by tile count, largest first (stable, so equal sizes keep the caller's order)
+        std::vector<int32_t> order((size_t)P);
+        for (int64_t r = 0; r < P; ++r) order[(size_t)r] = (int32_t)r;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](int32_t a2, int32_t b2) { return m->desc[(size_t)a2].nt > m->desc[(size_t)b2].nt; });
+        m->active_prefix.assign((size_t)m->max_nt + 2, 0);
+        for (int64_t r = 0; r < P; ++r)
+            for (int t = 0; t <= m->desc[(size_t)r].nt; ++t) ++m->active_prefix[(size_t)t];
+        if (hipMemcpy(m->d_order, order.data(), sizeof(int32_t) * (size_t)P, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("pmk_model_create: upload failed");
+            pmk_model_destroy(m);
+            return -100;
+        }
+    }
     {
         std::vector<double> hx((size_t)xo);
         for (int64_t r = 0; r < P; ++r) {
@@ -458,7 +490,12 @@ int pmk_model_create_ex(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const 
     }
     rc = upload_targets(m, y);
     if (rc) { pmk_model_destroy(m); return rc; }
-    PMK_HIP(hipMemset(m->d_info, 0, sizeof(int32_t) * (size_t)P));
+    // on the context's (non-blocking) stream: a null-stream memset would not be ordered with the fit that follows
+    if (hipMemsetAsync(m->d_info, 0, sizeof(int32_t) * (size_t)P, ctx->stream) != hipSuccess) {
+        set_error("pmk_model_create: memset failed");
+        pmk_model_destroy(m);
+        return -100;
+    }
     *out = m;
     return 0;
 }
@@ -481,43 +518,17 @@ int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)
     m->th = *th;
     m->sigma2 = sigma2;
     int rc;
-    const int G = (int)std::min<int64_t>(c->fit_groups, m->P);
-    if (c->timers || G <= 1) {
-        // one stream, stage by stage (the per-stage timers bracket whole stages)
-        c->tic("fit");
-        c->tic("kernel_matrix");
-        if (!c->fuse_k1 && (rc = PMK_BY_DTYPE(m, launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P)))) return rc;
-        c->toc("kernel_matrix");
-        c->tic("cholesky");
-        if ((rc = PMK_BY_DTYPE(m, launch_cholesky(m, c->stream, 0, m->P, c->fuse_k1)))) return rc;
-        c->toc("cholesky");
-        c->tic("solve");
-        if ((rc = PMK_BY_DTYPE(m, launch_backsolve(m, c->stream, 0, m->P)))) return rc;
-        c->toc("solve");
-        c->toc("fit");
-    } else {
-        // G independent sub-batches on side streams, forked from and joined back into the caller's stream
-        if (!c->fork) PMK_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
-        while ((int)c->aux.size() < G) {
-            hipStream_t st;
-            hipEvent_t ev;
-            PMK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            PMK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            c->aux.push_back(st);
-            c->aux_done.push_back(ev);
-        }
-        PMK_HIP(hipEventRecord(c->fork, c->stream));
-        for (int g = 0; g < G; ++g) {
-            const int64_t p0 = m->P * g / G, p1 = m->P * (g + 1) / G;
-            hipStream_t st = c->aux[(size_t)g];
-            PMK_HIP(hipStreamWaitEvent(st, c->fork, 0));
-            if (!c->fuse_k1 && (rc = PMK_BY_DTYPE(m, launch_kernel_matrix_slabs(m, *th, sigma2, st, p0, p1 - p0)))) return rc;
-            if ((rc = PMK_BY_DTYPE(m, launch_cholesky(m, st, p0, p1 - p0, c->fuse_k1)))) return rc;
-            if ((rc = PMK_BY_DTYPE(m, launch_backsolve(m, st, p0, p1 - p0)))) return rc;
-            PMK_HIP(hipEventRecord(c->aux_done[(size_t)g], st));
-            PMK_HIP(hipStreamWaitEvent(c->stream, c->aux_done[(size_t)g], 0));
-        }
-    }
+    c->tic("fit");
+    c->tic("kernel_matrix");
+    if ((rc = PMK_BY_DTYPE(m, launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P)))) return rc;
+    c->toc("kernel_matrix");
+    c->tic("cholesky");
+    if ((rc = PMK_BY_DTYPE(m, launch_cholesky(m, c->stream, 0, m->P)))) return rc;
+    c->toc("cholesky");
+    c->tic("solve");
+    if ((rc = PMK_BY_DTYPE(m, launch_backsolve(m, c->stream, 0, m->P)))) return rc;
+    c->toc("solve");
+    c->toc("fit");
     m->fitted = true;
     return 0;
 }
@@ -561,20 +572,18 @@ int pmk_model_get(pmk_model *m, int64_t patch, int what, double *out, int64_t ld
         // U_set entry (mixtureGP.jl:99): K without noise, rebuilt on demand from the resident points
         if (ld < d.n) { set_error("pmk_model_get: ld too small"); return -5; }
         if (!kernel_ok(&m->th)) { set_error("pmk_model_get: no kernel set (fit first)"); return -3; }
-        double *dK = nullptr, *dxs = nullptr;
-        if (dev_alloc(&dK, (int64_t)d.n * d.n) || dev_alloc(&dxs, (int64_t)d.ld * m->D)) return -100;
+        DevTmp<double> dK, dxs;
+        if (dK.alloc((int64_t)d.n * d.n) || dxs.alloc((int64_t)d.ld * m->D)) return -100;
         {   // the dense host-API kernel is fp64: give it fp64 coordinates whatever the model's element type
             std::vector<double> hx((size_t)(d.ld * m->D));
             if (int rc2 = download_real_2d(m, hx.data(), d.ld, m->d_x, d.xoff, d.ld, d.ld, m->D, c->stream)) return rc2;
             PMK_HIP(hipMemcpy(dxs, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
         }
         int rc = launch_kernel_matrix_dense(m->th, m->D, d.n, dxs, d.ld, d.n, dxs, d.ld, dK, d.n, true, c->stream);
-        if (!rc) {
+        if (!rc)
             PMK_HIP(hipMemcpy2DAsync(out, sizeof(double) * ld, dK, sizeof(double) * d.n, sizeof(double) * d.n, (size_t)d.n,
                                      hipMemcpyDeviceToHost, c->stream));
-            PMK_HIP(hipStreamSynchronize(c->stream));
-        }
-        dev_free(dK); dev_free(dxs);
+        PMK_HIP(hipStreamSynchronize(c->stream));
         return rc;
     }
     case PMK_GET_LINV_DIAG:
@@ -623,13 +632,20 @@ int pmk_model_load(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const doubl
             if (j < d.n) for (int64_t i = j; i < d.n; ++i) slab[(size_t)(i + j * d.ld)] = L[r][i + j * ldl[r]];
             else slab[(size_t)(j + j * d.ld)] = 1.0;                      // identity padding
         }
-        if ((rc = upload_real(m, m->d_a, d.aoff, slab.data(), slab.size()))) return rc;
         std::vector<double> cc((size_t)d.ld, 0.0);
         std::memcpy(cc.data(), c[r], sizeof(double) * (size_t)d.n);
-        if ((rc = upload_real(m, m->d_c, d.yoff, cc.data(), cc.size()))) return rc;
+        if ((rc = upload_real(m, m->d_a, d.aoff, slab.data(), slab.size())) ||
+            (rc = upload_real(m, m->d_c, d.yoff, cc.data(), cc.size()))) {
+            pmk_model_destroy(m);
+            *out = nullptr;
+            return rc;
+        }
     }
-    if ((rc = PMK_BY_DTYPE(m, launch_ninv_from_slabs(m, ctx->stream)))) { pmk_model_destroy(m); *out = nullptr; return rc; }
-    PMK_HIP(hipStreamSynchronize(ctx->stream));
+    if (!(rc = PMK_BY_DTYPE(m, launch_ninv_from_slabs(m, ctx->stream))) && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        set_error("pmk_model_load: %s", hipGetErrorString(hipGetLastError()));
+        rc = -100;
+    }
+    if (rc) { pmk_model_destroy(m); *out = nullptr; return rc; }
     m->fitted = true;
     return 0;
 }
@@ -746,7 +762,7 @@ int pmk_query_create(pmk_model *m, int64_t Nq, const double *Xq, pmk_query **out
     PMK_HIP(hipSetDevice(m->ctx->device));
     pmk_query *q = new (std::nothrow) pmk_query();
     if (!q) { set_error("out of memory"); return -100; }
-    q->m = m; q->Nq = Nq;
+    q->m = m; q->Nq = Nq; q->roff_P = m->P_global;
     int rc = 0;
     rc |= dev_alloc(&q->d_xq, Nq * m->D);
     rc |= dev_alloc(&q->d_home, Nq);
@@ -828,6 +844,11 @@ int pmk_query_plan(pmk_query *q, double radius, double delta)
     pmk_ctx *c = m->ctx;
     PMK_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    if (m->P_global != q->roff_P) {
+        set_error("pmk_query_plan: the model's tree changed (%lld -> %lld leaves) after the query was created",
+                  (long long)q->roff_P, (long long)m->P_global);
+        return -4;
+    }
     c->tic("plan");
     q->planned = false;
     q->total = 0;

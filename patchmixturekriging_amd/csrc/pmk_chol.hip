@@ -2,23 +2,28 @@
 // solves for the GP weights.  Replaces, per patch, `cholesky(U)` and `c = U\y` of the reference
 // (src/RKHS/mixtureGP.jl:106-112): one factorisation serves both.
 //
-// Step k of the factorisation (k = 0 .. nt-1), all patches at once, two launches:
-//   chol_diag_kernel  : one workgroup per patch.  Applies the last block column to the diagonal tile
-//                       (A[kk] -= L[k,k-1] L[k,k-1]^T, MFMA, in place in the slab), factors it with the tile
-//                       distributed over the registers of the 256 threads (right-looking, two barriers per
-//                       pivot), stores L[kk] and the negated inverses of its four 32 x 32 diagonal blocks
-//                       (every later TRSM is MFMA block substitution with them); the right-hand side rides
-//                       along as an extra row, so z_k = L[kk]^-1 (y_k - L[k,0:k] z_0:k) falls out of the
-//                       same elimination.
-//   chol_panel_kernel : grid over the block rows below + one "look-ahead" workgroup per patch.
-//                       Block rows: T = A[i,k] - L[i,0:k] L[k,0:k]^T on MFMA (the contraction the north
-//                       star prices), then L[i,k] = T L[kk]^-T by in-register block substitution.
-//                       Look-ahead workgroup: applies block columns 0..k-1 to the NEXT diagonal tile
-//                       (A[k+1,k+1] -= L[k+1,0:k] L[k+1,0:k]^T) and to the next forward-solve piece, so
-//                       the serial diagonal kernel only ever sees one block column of GEMM.
+//   chol_first_kernel : one workgroup per patch: potrf of the first diagonal tile A[0,0] (+ its inverted
+//                       32 x 32 diagonal blocks and z_0 = L[00]^-1 y_0).
+//   chol_step_kernel  : block column k of every active patch, one launch.  Workgroup = one 128-row block row i > k:
+//                           T = A[i,k] - L[i,0:k] L[k,0:k]^T      (MFMA: the contraction the north star prices)
+//                           L[i,k] = T L[kk]^-T                    (in-register block substitution on MFMA)
+//                       The workgroup of block row k+1 is the CRITICAL one and continues alone:
+//                           A[k+1,k+1] -= L[k+1,0:k+1] L[k+1,0:k+1]^T   (look-ahead, MFMA; column k it has just made)
+//                           rhs = y_{k+1} - L[k+1,0:k+1] z_{0:k+1}
+//                           potrf of the tile in registers -> L[k+1,k+1], -D^-1 blocks, z_{k+1}
+//                       so the next launch finds its diagonal block ready: there is no separate (serial,
+//                       latency-bound) diagonal launch between two steps, its ~90 us per step hide behind the
+//                       other block rows of the same launch.  The critical workgroups get the lowest logical ids
+//                       of their XCD, so they are dispatched first.
+// Schedule: END-ALIGNED.  Patch p (nt_p tiles) runs its block column k at launch l = k + (max_nt - nt_p): every
+// active patch then has exactly max_nt - l - 1 block rows below the diagonal (the grid has no empty workgroups),
+// and the long last steps always see every patch -- ragged batches do not end in launches that only the largest
+// patches populate.  Patches are visited through `order` (sorted by nt, largest first): the active ones are a prefix.
 // The slab is read once per block column (left-looking): reads only, no trailing-matrix
 // read-modify-write.  chol_backsolve_kernel then gives c = L^-T z.
+#include <algorithm>
 #include <cstdlib>
+#include <numeric>
 
 #include "pmk_mfma.h"
 
@@ -33,65 +38,241 @@ constexpr int PFJ_CHOL = PMK_PFJ;   // J-operand (own rows, HBM) prefetch depth
 constexpr int PF_DIAG = 4;
 constexpr int SB = 32;          // sub-block of the in-LDS potrf and of the TRSM block substitution
 
-// Fused kernel-matrix build (K1 folded into the factorisation): entry (i, j) of U = K + sigma2 I of a
-// patch, evaluated from the resident coordinates exactly as constructkernelmatrix! + the diagonal update
-// do (row point first for i >= j, mirrored above; src/RKHS/RKHS.jl:21-31, mixtureGP.jl:102-104), with the
-// identity padding of the slab.  FUSE = 0 reads the value kmat_slab_kernel wrote instead.
-template <int D, int FAM>
-struct TileSource {
-    const real *xs;     // SoA coordinates of the patch
-    int64_t ld;
-    int n;
-    real sigma2;
-    pmk_kernel_desc th;
-    __device__ __forceinline__ void point(int i, real *p) const
-    {
-#pragma unroll
-        for (int d = 0; d < D; ++d) p[d] = xs[(int64_t)d * ld + i];
-    }
-    __device__ __forceinline__ real value(int i, const real *pi, int j, const real *pj) const
-    {
-        real v = (i >= j) ? kern_eval<D, FAM, real>(th, pi, pj) : kern_eval<D, FAM, real>(th, pj, pi);
-        v = (i == j) ? v + sigma2 : v;
-        const bool inside = i < n && j < n;
-        return inside ? v : ((i == j) ? 1.0 : 0.0);
-    }
-};
+// LDS of a factorisation workgroup: first the TRSM operands of the block row (TRI_LDS_DOUBLES), later -- in the
+// critical workgroup, once the block substitution is done -- the scratch of the tile potrf, carved from the same array
+constexpr int POTRF_DBLK = 0;                               // [4][SB][SB+1] the four diagonal 32 x 32 blocks of L[kk]
+constexpr int POTRF_COL = POTRF_DBLK + 4 * SB * (SB + 1);   // [TILE+1] scaled pivot column; [TILE] = forward-solve entry
+constexpr int POTRF_RHS = POTRF_COL + TILE + 8;             // [2*TILE]
+constexpr int POTRF_SDIAG = POTRF_RHS + 2 * TILE;           // [1]
+constexpr int POTRF_BAD = POTRF_SDIAG + 2;                  // int
+constexpr int POTRF_END = POTRF_BAD + 2;
+static_assert(POTRF_END <= TRI_LDS_DOUBLES, "potrf scratch must fit into the TRSM operand array");
 
 // ---------------------------------------------------------------------------------------------
-// diagonal block
+// potrf of one 128 x 128 diagonal tile (already updated, lower part in the slab at Akk), right-looking, the tile
+// distributed over the registers of all 256 threads: thread (tr, tc) of a 16 x 16 grid holds
+// A[tr + 16 a][tc + 16 b], a, b < 8; the threads with tr == 0 also carry the right-hand side (lds[POTRF_RHS + 0..127],
+// written by the caller before a barrier) as an extra row, which the elimination turns into z = L[kk]^-1 rhs.
+// Per pivot: the 16 threads that own column j scale it and publish it through LDS, one barrier, every thread applies
+// the rank-1 update to its own entries, one barrier.  The pivot's reciprocal square root comes from v_rsq + Newton
+// steps: the 128 pivots are a serial latency chain, this is its critical path.
+// Writes L[kk] (strict upper part of the slab block zeroed), the negated inverses of its four 32 x 32 diagonal
+// blocks (operands of every later block substitution), z, and info (first non-positive pivot, 1-based, once).
+// Must be entered by all 256 threads; the caller has synchronised after its last write to Akk and rhs.
 // ---------------------------------------------------------------------------------------------
-template <int D, int FAM, int FUSE>
-__global__ __launch_bounds__(256, 2) void chol_diag_kernel(const PatchDesc *__restrict__ descs, real *__restrict__ A,
-                                                           real *__restrict__ ninv, const real *__restrict__ y,
-                                                           const real *__restrict__ ytmp, real *__restrict__ z,
-                                                           int32_t *__restrict__ info, int k,
-                                                           const real *__restrict__ x, pmk_kernel_desc th, double sigma2,
-                                                           int skip)
+__device__ __forceinline__ void tile_potrf(real *__restrict__ Akk, int64_t ld, real *lds,
+                                           real *__restrict__ ninv_k, real *__restrict__ z_k,
+                                           int32_t *__restrict__ info_p, int k)
 {
-    const PatchDesc pd = descs[blockIdx.x];
-    if (k >= pd.nt) return;
-    // LDS stays small (~38 KB, 256 registers): the tile itself lives in the slab (L2) and in registers, so a
-    // diagonal workgroup can share a CU with a panel workgroup of another sub-batch (PMK_FIT_GROUPS)
-    __shared__ real dblk[4][SB][SB + 1];     // the four 32 x 32 diagonal blocks of L[kk], for their inversion
-    __shared__ real col[TILE + 1];           // scaled pivot column; col[TILE] = the forward-solve entry z_j
-    __shared__ real rhs[2 * TILE];
-    __shared__ real sdiag;
-    __shared__ int s_bad;
-
+#define DBLK(b, i, j) lds[POTRF_DBLK + ((b) * SB + (i)) * (SB + 1) + (j)]
+#define COL(i) lds[POTRF_COL + (i)]
+#define SDIAG lds[POTRF_SDIAG]
+#define SBAD lds[POTRF_BAD]          /* first failed pivot (1-based) as a real: exact up to 2^24 */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = wave >> 1, g = wave & 1;          // 64-row half, 64-column half of the tile
+    const int tr = tid & 15, tc = tid >> 4;
+    real a_[8][8], rr[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 8; ++b2)
+            a_[a][b2] = (b2 <= a) ? Akk[(tr + 16 * a) + (int64_t)(tc + 16 * b2) * ld] : (real)0;
+#pragma unroll
+    for (int b2 = 0; b2 < 8; ++b2) rr[b2] = lds[POTRF_RHS + tc + 16 * b2];
+    if (tid == 0) { SDIAG = a_[0][0]; SBAD = 0; }
+    __syncthreads();
+    // two-level pivot loop: the 16-column block index bj is a compile-time constant in each copy of the body, so
+    // a_[.][bj] is a static register reference and the update loops run over exactly the live blocks -- no
+    // per-pivot scalar branches (an earlier version guarded every 16 x 16 block with a runtime test: ~40
+    // s_cbranch per pivot cost more than the arithmetic they skipped)
+#pragma unroll
+    for (int bj = 0; bj < 8; ++bj) {
+#pragma clang loop unroll(disable)      // 128 unrolled pivot bodies cross-schedule into hundreds of spilled registers
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * bj + jj;
+            if (tc == jj) {
+                real d = SDIAG;
+                if (!(d > (real)0)) {                     // not positive definite (or NaN): record, keep going
+                    if (tr == 0 && SBAD == (real)0) SBAD = (real)(k * TILE + j + 1);
+                    d = 1;
+                }
+                const real rs = rsqrt_real(d);
+                const real ljj = d * rs;
+#pragma unroll
+                for (int a = bj; a < 8; ++a) {
+                    const int r = tr + 16 * a;
+                    const real v = (r > j) ? a_[a][bj] * rs : ((r == j) ? ljj : a_[a][bj]);
+                    a_[a][bj] = v;
+                    COL(r) = (r > j) ? v : (real)0;
+                }
+                if (tr == 0) {                            // the extra row: z_j = rhs_j / L[j][j]
+                    rr[bj] = rr[bj] * rs;
+                    COL(TILE) = rr[bj];
+                }
+            }
+            __syncthreads();
+            real cr[8], cc[8];
+#pragma unroll
+            for (int a = bj; a < 8; ++a) { cr[a] = COL(tr + 16 * a); cc[a] = COL(tc + 16 * a); }
+#pragma unroll
+            for (int a = bj; a < 8; ++a)
+#pragma unroll
+                for (int b2 = bj; b2 <= a; ++b2) a_[a][b2] -= cr[a] * cc[b2];   // col[] is 0 for rows <= j
+            if (tr == 0) {
+                const real zj = COL(TILE);
+#pragma unroll
+                for (int b2 = bj; b2 < 8; ++b2) rr[b2] -= zj * cc[b2];
+            }
+            // publish the next pivot's diagonal entry: A[j+1][j+1] lives in block (bj, bj), or in block
+            // (bj+1, bj+1) of thread (0, 0) when j+1 starts the next block
+            if (jj < 15) {
+                if (tr == jj + 1 && tc == jj + 1) SDIAG = a_[bj][bj];
+            } else if (bj < 7) {
+                if (tid == 0) SDIAG = a_[bj + 1 < 8 ? bj + 1 : 7][bj + 1 < 8 ? bj + 1 : 7];
+            }
+            __syncthreads();
+        }
+    }
+    // ---- L[kk] -> slab (lower; the strict upper part of the slab block is zeroed), the four diagonal
+    //      32 x 32 blocks -> LDS for their inversion, z_k -> global
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 8; ++b2) {
+            const int r = tr + 16 * a, c = tc + 16 * b2;
+            const real v = (b2 <= a && r >= c) ? a_[a][b2] : (real)0;
+            Akk[r + (int64_t)c * ld] = v;
+            if ((r >> 5) == (c >> 5)) DBLK(r >> 5, r & 31, c & 31) = v;
+        }
+    if (tr == 0) {
+#pragma unroll
+        for (int b2 = 0; b2 < 8; ++b2) z_k[tc + 16 * b2] = rr[b2];
+    }
+    __syncthreads();
+    if (tid == 0 && SBAD != (real)0 && *info_p == 0) *info_p = (int32_t)SBAD;
+    // ---- negated inverses of the four 32 x 32 diagonal blocks: wave w inverts block w, one thread per column
+    if (lane < SB) {
+        const int c = lane;
+        real xcol[SB];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            real sacc = (i == c) ? (real)1 : (real)0;
+#pragma unroll
+            for (int l = 0; l < i; ++l) sacc -= DBLK(wave, i, l) * xcol[l];
+            xcol[i] = sacc / DBLK(wave, i, i);
+        }
+        real *Ni = ninv_k + (int64_t)wave * (SB * SB);
+#pragma unroll
+        for (int i = 0; i < SB; ++i) Ni[i + SB * c] = (i >= c) ? -xcol[i] : (real)0;
+    }
+#undef DBLK
+#undef COL
+#undef SDIAG
+#undef SBAD
+}
+
+// first diagonal tile of every patch: nothing to apply, rhs = y_0
+__global__ __launch_bounds__(256, 2) void chol_first_kernel(const PatchDesc *__restrict__ descs, real *__restrict__ A,
+                                                            real *__restrict__ ninv, const real *__restrict__ y,
+                                                            real *__restrict__ z, int32_t *__restrict__ info)
+{
+    __shared__ real lds[POTRF_END];
+    const PatchDesc pd = descs[blockIdx.x];
+    if (threadIdx.x < TILE) lds[POTRF_RHS + threadIdx.x] = y[pd.yoff + threadIdx.x];
+    __syncthreads();
+    tile_potrf(A + pd.aoff, pd.ld, lds, ninv + pd.ioff, z + pd.yoff, info + blockIdx.x, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one block column of every active patch.  Workgroup = one 128-row block row = 4 waves x (32 rows x 128 columns);
+// in the GEMM + TRSM part the waves are independent (no barrier after the operand staging) and two workgroups
+// share a CU (2 waves per SIMD).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__restrict__ descs,
+                                                           const int32_t *__restrict__ order, int nactive, int G,
+                                                           int launch, int max_nt, real *__restrict__ A,
+                                                           real *__restrict__ ninv, const real *__restrict__ y,
+                                                           real *__restrict__ z, int32_t *__restrict__ info)
+{
+    __shared__ real lds[TRI_LDS_DOUBLES];
+    // logical (patch slot, block row) from the XCD-aware id: the workgroups of a patch land on one XCD and share the
+    // I-operand (block row k of L) through that XCD's L2; within an XCD the critical workgroups (bx == 0) come first
+    const int nwg = nactive * G;
+    const int lid = xcd_remap(blockIdx.x, nwg);
+    int slot, bx;
+    if (G == 1) {
+        slot = lid; bx = 0;
+    } else if ((nactive & 7) == 0) {
+        const int per = nactive >> 3, chunk = per * G;
+        const int xcd = lid / chunk, loc = lid - xcd * chunk;
+        if (loc < per) { slot = xcd * per + loc; bx = 0; }
+        else { const int j = loc - per; slot = xcd * per + j / (G - 1); bx = 1 + j % (G - 1); }
+    } else {
+        if (lid < nactive) { slot = lid; bx = 0; }
+        else { const int j = lid - nactive; slot = j / (G - 1); bx = 1 + j % (G - 1); }
+    }
+    const int pid = order[slot];
+    const PatchDesc pd = descs[pid];
+    const int k = launch - (max_nt - pd.nt);      // this patch's block column (end-aligned schedule): 0 <= k < nt - 1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     real *S = A + pd.aoff;
     const int64_t ld = pd.ld;
-    const int64_t d0 = (int64_t)k * TILE;
-    real *Akk = S + d0 + d0 * ld;
-    if (tid == 0) s_bad = 0;
+    const int64_t c0 = (int64_t)k * TILE;
 
-    // ---- A[kk] -= L[k,k-1] L[k,k-1]^T in place in the slab (older block columns were applied by the look-ahead
-    //      workgroup of the previous panel launch); lower 64 x 64 sub-tiles only
-    if (!(h == 0 && g == 1) && ((k > 0 && !(skip & 16)) || (FUSE && k == 0))) {
-        // acc starts as -A[kk] (all of the sub-tile's loads in flight at once; read-modify-write per element made
-        // hipcc serialise 16 L2 round trips behind the GEMM), the GEMM adds L L^T, the store negates
+    // ---- block row k + 1 + bx of block column k
+    {
+        const int64_t r0 = (int64_t)(k + 1 + bx) * TILE + 32 * wave;
+        real *out = S + r0 + 2 * (lane & 15) + c0 * ld;   // rows of this lane, first column of the block column
+        // acc starts as -A[rows, block column k]; the GEMM adds L[rows,0:k] L[k,0:k]^T, so acc = -T.  The tile comes
+        // from HBM (first touch): its loads are issued before the operand staging so that the two latencies overlap
+        // instead of adding up.
+        WaveTile<4, 1> acc;   // I = the 128 columns of block column k, J = 32 rows
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = tile_i(fi, lane, q);
+                const real2_t a = *reinterpret_cast<const real2_t *>(out + cl * ld);
+                acc.f[fi][0][q] = a[0];
+                acc.f[fi][1][q] = a[1];
+            }
+        __builtin_amdgcn_sched_barrier(0);      // keep the tile loads ahead of the staging loads
+        // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per workgroup
+        stage_tri_operands(lds, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc.f[fi][0][q] = -acc.f[fi][0][q];
+                acc.f[fi][1][q] = -acc.f[fi][1][q];
+            }
+        __syncthreads();
+        if (k > 0) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
+        // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
+        tri_solve_inplace<1>(acc, lds, lane);
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = tile_i(fi, lane, q);
+                real2_t o;
+                o[0] = acc.f[fi][0][q];
+                o[1] = acc.f[fi][1][q];
+                *reinterpret_cast<real2_t *>(out + cl * ld) = o;
+            }
+    }
+    if (bx != 0) return;
+
+    // ================= critical workgroup: look-ahead + potrf of diagonal tile k + 1 =================
+    // all four waves have stored their rows of L[k+1, k] (same CU: visible through its L1 after the barrier), and
+    // nobody reads the TRSM operands in LDS any more
+    __syncthreads();
+    const int64_t t0 = c0 + TILE;
+    const int K2 = (k + 1) * TILE;                    // block columns 0..k
+    const int h = wave >> 1, g = wave & 1;            // 64-row half, 64-column half of the tile
+    real *Att = S + t0 + t0 * ld;
+    if (!(h == 0 && g == 1)) {
+        // A[k+1,k+1] -= L[k+1,0:k+1] L[k+1,0:k+1]^T, lower 64 x 64 sub-tiles: acc = -A up-front (all the sub-tile's
+        // loads in flight at once), the GEMM adds L L^T, the store negates
         WaveTile<2, 2> acc;
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
@@ -101,23 +282,11 @@ __global__ __launch_bounds__(256, 2) void chol_diag_kernel(const PatchDesc *__re
                 for (int pj = 0; pj < 2; ++pj) {
                     const int cl = 64 * g + tile_i(fi, lane, q);
                     const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
-                    real2_t a;
-                    if (FUSE && k == 0) {          // first tile: nothing was written to the slab, evaluate K here
-                        const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
-                        real pc[D], pr0[D], pr1[D];
-                        src.point(cl, pc); src.point(rl, pr0); src.point(rl + 1, pr1);
-                        a[0] = src.value(rl, pr0, cl, pc);
-                        a[1] = src.value(rl + 1, pr1, cl, pc);
-                    } else {
-                        a = *reinterpret_cast<const real2_t *>(Akk + rl + (int64_t)cl * ld);
-                    }
+                    const real2_t a = *reinterpret_cast<const real2_t *>(Att + rl + (int64_t)cl * ld);
                     acc.f[fi][2 * pj][q] = -a[0];
                     acc.f[fi][2 * pj + 1][q] = -a[1];
                 }
-        if (k > 0) {
-            const real *Lk = S + d0 + (d0 - TILE) * ld;      // L[k, k-1]: 128 x 128
-            gemm_nt<2, 2, PF_DIAG>(acc, Lk + 64 * g, ld, Lk + 64 * h, ld, TILE, lane);
-        }
+        gemm_nt<2, 2, PF_DIAG>(acc, S + t0 + 64 * g, ld, S + t0 + 64 * h, ld, K2, lane);
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
@@ -129,288 +298,30 @@ __global__ __launch_bounds__(256, 2) void chol_diag_kernel(const PatchDesc *__re
                     real2_t a;
                     a[0] = -acc.f[fi][2 * pj][q];
                     a[1] = -acc.f[fi][2 * pj + 1][q];
-                    *reinterpret_cast<real2_t *>(Akk + rl + (int64_t)cl * ld) = a;
+                    *reinterpret_cast<real2_t *>(Att + rl + (int64_t)cl * ld) = a;
                 }
-    }
-    // ---- forward-solve right-hand side: y_k - L[k,0:k-1] z (look-ahead) - L[k,k-1] z_{k-1}
-    {
-        const int row = tid & 127, half = tid >> 7;
-        real s = 0.0;
-        if (k > 0) {
-            const real *Lr = S + d0 + row + (d0 - TILE + 64 * half) * ld;
-            const real *zz = z + pd.yoff + d0 - TILE + 64 * half;
-            for (int cb = 0; cb < 64; cb += 16) {          // 16 independent column loads in flight per batch
-                real lv[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) lv[c] = Lr[(int64_t)(cb + c) * ld];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) s += lv[c] * zz[cb + c];
-            }
-        }
-        rhs[tid] = s;
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (tid < TILE) {
-        const real base = (k == 0) ? y[pd.yoff + tid] : ytmp[pd.yoff + d0 + tid];
-        rhs[tid] = base - (rhs[tid] + rhs[tid + TILE]);
-    }
-    __syncthreads();
-
-    // ---- potrf of the tile: right-looking, the tile distributed over the registers of all 256 threads
-    //      (thread (tr, tc) of a 16 x 16 grid holds A[tr + 16 a][tc + 16 b], a, b < 8; the threads with tr == 0
-    //      also carry the right-hand side as an extra row, which the elimination turns into z_k = L[kk]^-1 rhs).
-    //      Per pivot: the 16 threads that own column j scale it and publish it through LDS, one barrier, every
-    //      thread applies the rank-1 update to its own entries, one barrier.  The pivot's reciprocal square root
-    //      comes from v_rsq + Newton steps: the 128 pivots are a serial latency chain, this is its critical path.
-    {
-        const int tr = tid & 15, tc = tid >> 4;
-        real a_[8][8], rr[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int b2 = 0; b2 < 8; ++b2)
-                a_[a][b2] = (b2 <= a) ? Akk[(tr + 16 * a) + (int64_t)(tc + 16 * b2) * ld] : (real)0;
-#pragma unroll
-        for (int b2 = 0; b2 < 8; ++b2) rr[b2] = rhs[tc + 16 * b2];
-        if (tid == 0) sdiag = a_[0][0];
-        __syncthreads();
-        // two-level pivot loop: the 16-column block index bj is a compile-time constant in each copy of the body, so
-        // a_[.][bj] is a static register reference and the update loops run over exactly the live blocks -- no
-        // per-pivot scalar branches (an earlier version guarded every 16 x 16 block with a runtime test: ~40
-        // s_cbranch per pivot cost more than the arithmetic they skipped)
-#pragma unroll
-        for (int bj = 0; bj < 8; ++bj) {
-            for (int jj = 0; jj < ((skip & 1) ? 0 : 16); ++jj) {
-                const int j = 16 * bj + jj;
-                if (tc == jj) {
-                    real d = sdiag;
-                    if (!(d > (real)0)) {                     // not positive definite (or NaN): record, keep going
-                        if (tr == 0 && s_bad == 0) s_bad = k * TILE + j + 1;
-                        d = 1;
-                    }
-                    const real rs = rsqrt_real(d);
-                    const real ljj = d * rs;
-#pragma unroll
-                    for (int a = bj; a < 8; ++a) {
-                        const int r = tr + 16 * a;
-                        const real v = (r > j) ? a_[a][bj] * rs : ((r == j) ? ljj : a_[a][bj]);
-                        a_[a][bj] = v;
-                        col[r] = (r > j) ? v : (real)0;
-                    }
-                    if (tr == 0) {                            // the extra row: z_j = rhs_j / L[j][j]
-                        rr[bj] = rr[bj] * rs;
-                        col[TILE] = rr[bj];
-                    }
-                }
-                __syncthreads();
-                real cr[8], cc[8];
-#pragma unroll
-                for (int a = bj; a < 8; ++a) { cr[a] = col[tr + 16 * a]; cc[a] = col[tc + 16 * a]; }
-#pragma unroll
-                for (int a = bj; a < 8; ++a)
-#pragma unroll
-                    for (int b2 = bj; b2 <= a; ++b2) a_[a][b2] -= cr[a] * cc[b2];   // col[] is 0 for rows <= j
-                if (tr == 0) {
-                    const real zj = col[TILE];
-#pragma unroll
-                    for (int b2 = bj; b2 < 8; ++b2) rr[b2] -= zj * cc[b2];
-                }
-                // publish the next pivot's diagonal entry: A[j+1][j+1] lives in block (bj, bj), or in block
-                // (bj+1, bj+1) of thread (0, 0) when j+1 starts the next block
-                if (jj < 15) {
-                    if (tr == jj + 1 && tc == jj + 1) sdiag = a_[bj][bj];
-                } else if (bj < 7) {
-                    if (tid == 0) sdiag = a_[bj + 1 < 8 ? bj + 1 : 7][bj + 1 < 8 ? bj + 1 : 7];
-                }
-                __syncthreads();
-            }
-        }
-        // ---- L[kk] -> slab (lower; the strict upper part of the slab block is zeroed), the four diagonal
-        //      32 x 32 blocks -> LDS for their inversion, z_k -> global
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int b2 = 0; b2 < 8; ++b2) {
-                const int r = tr + 16 * a, c = tc + 16 * b2;
-                const real v = (b2 <= a && r >= c) ? a_[a][b2] : (real)0;
-                if (!(skip & 4)) Akk[r + (int64_t)c * ld] = v;
-                if ((r >> 5) == (c >> 5)) dblk[r >> 5][r & 31][c & 31] = v;
-            }
-        if (tr == 0) {
-#pragma unroll
-            for (int b2 = 0; b2 < 8; ++b2) z[pd.yoff + d0 + tc + 16 * b2] = rr[b2];
-        }
-    }
-    __syncthreads();
-    if (tid == 0 && s_bad && info[blockIdx.x] == 0) info[blockIdx.x] = s_bad;
-    // ---- negated inverses of the four 32 x 32 diagonal blocks: wave w inverts block w, one thread per column
-    if (lane < SB && !(skip & 2)) {
-        const int c = lane;
-        real xcol[SB];
-#pragma unroll
-        for (int i = 0; i < SB; ++i) {
-            real sacc = (i == c) ? (real)1 : (real)0;
-#pragma unroll
-            for (int l = 0; l < i; ++l) sacc -= dblk[wave][i][l] * xcol[l];
-            xcol[i] = sacc / dblk[wave][i][i];
-        }
-        real *Ni = ninv + pd.ioff + (int64_t)k * (4 * SB * SB) + (int64_t)wave * (SB * SB);
-#pragma unroll
-        for (int i = 0; i < SB; ++i) Ni[i + SB * c] = (i >= c) ? -xcol[i] : (real)0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// block column below the diagonal: MFMA update + in-register TRSM, plus the look-ahead workgroup
-// block-row workgroup = one 128-row tile = 4 waves x (32 rows x 128 columns); the waves are
-// independent (no LDS, no barrier) and two workgroups share a CU (2 waves per SIMD)
-// ---------------------------------------------------------------------------------------------
-template <int D, int FAM, int FUSE>
-__global__ __launch_bounds__(256, 2) void chol_panel_kernel(const PatchDesc *__restrict__ descs, real *__restrict__ A,
-                                                            const real *__restrict__ ninv, const real *__restrict__ y,
-                                                            const real *__restrict__ z, real *__restrict__ ytmp, int k,
-                                                            const real *__restrict__ x, pmk_kernel_desc th, double sigma2)
-{
-    // logical (block row, patch) from the XCD-aware id: all workgroups of a patch land on one XCD and
-    // share the I-operand (block row k of L) through that XCD's L2
-    const int lid = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
-    const int bx = lid % gridDim.x;
-    const PatchDesc pd = descs[lid / gridDim.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    real *S = A + pd.aoff;
-    const int64_t ld = pd.ld;
-    const int64_t c0 = (int64_t)k * TILE;
-
-    if (bx == (int)gridDim.x - 1) {
-        // ---- look-ahead for diagonal tile k+1: block columns 0..k-1 (column k is being produced by
-        //      this very launch and is applied by the next diagonal kernel)
-        const int64_t t0 = c0 + TILE;
-        if (k + 1 >= pd.nt) return;
-        const int h = wave >> 1, g = wave & 1;
-        if ((k > 0 || FUSE) && !(h == 0 && g == 1)) {
-            // acc = -A[k+1,k+1] (or -K evaluated) up-front, GEMM adds L L^T, the store negates (see diag_kernel)
-            WaveTile<2, 2> acc;
-            real *Att = S + t0 + t0 * ld;
-            const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int pj = 0; pj < 2; ++pj) {
-                        const int cl = 64 * g + tile_i(fi, lane, q);
-                        const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
-                        real2_t a;
-                        if (FUSE) {
-                            real pc[D], pr0[D], pr1[D];
-                            const int gc = (int)t0 + cl, gr = (int)t0 + rl;
-                            src.point(gc, pc); src.point(gr, pr0); src.point(gr + 1, pr1);
-                            a[0] = src.value(gr, pr0, gc, pc);
-                            a[1] = src.value(gr + 1, pr1, gc, pc);
-                        } else {
-                            a = *reinterpret_cast<const real2_t *>(Att + rl + (int64_t)cl * ld);
-                        }
-                        acc.f[fi][2 * pj][q] = -a[0];
-                        acc.f[fi][2 * pj + 1][q] = -a[1];
-                    }
-            if (k > 0) gemm_nt<2, 2, PF_DIAG>(acc, S + t0 + 64 * g, ld, S + t0 + 64 * h, ld, k * TILE, lane);
-#pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int pj = 0; pj < 2; ++pj) {
-                        const int cl = 64 * g + tile_i(fi, lane, q);
-                        const int rl = 64 * h + 32 * pj + 2 * (lane & 15);
-                        real2_t a;
-                        a[0] = -acc.f[fi][2 * pj][q];
-                        a[1] = -acc.f[fi][2 * pj + 1][q];
-                        *reinterpret_cast<real2_t *>(Att + rl + (int64_t)cl * ld) = a;
-                    }
-        }
-        if (h == 0 && g == 1) {
-            // the wave without a GEMM sub-tile does the forward-solve piece: two rows per lane
-            const real *Lr = S + t0 + 2 * lane;
-            const real *zz = z + pd.yoff;
-            real2_t s0 = {0.0, 0.0}, s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, s3 = {0.0, 0.0};
-            for (int c = 0; c < k * TILE; c += 16) {     // 16 independent column loads in flight per batch
-                real2_t av[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) av[u] = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + u) * ld);
-#pragma unroll
-                for (int u = 0; u < 16; u += 4) {
-                    s0 += av[u] * zz[c + u]; s1 += av[u + 1] * zz[c + u + 1];
-                    s2 += av[u + 2] * zz[c + u + 2]; s3 += av[u + 3] * zz[c + u + 3];
-                }
-            }
-            const real2_t sum = (s0 + s1) + (s2 + s3);
-            const real2_t yy = *reinterpret_cast<const real2_t *>(y + pd.yoff + t0 + 2 * lane);
-            *reinterpret_cast<real2_t *>(ytmp + pd.yoff + t0 + 2 * lane) = yy - sum;
-        }
-        return;
-    }
-
-    // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per workgroup
-    if ((int64_t)(k + 1 + bx) * TILE >= pd.ld) return;      // whole workgroup: ld is a multiple of TILE
-    __shared__ real tri[TRI_LDS_DOUBLES];
-    const int64_t r0 = (int64_t)(k + 1 + bx) * TILE + 32 * wave;
-    real *out = S + r0 + 2 * (lane & 15) + c0 * ld;   // rows of this lane, first column of the block column
-
-    // acc starts as -A[rows, block column k]; the GEMM adds L[rows,0:k] L[k,0:k]^T, so acc = -T.  The tile comes
-    // from HBM (first touch): its loads are issued before the operand staging so that the two latencies overlap
-    // instead of adding up.
-    WaveTile<4, 1> acc;   // I = the 128 columns of block column k, J = 32 rows
-    if (FUSE) {
-        stage_tri_operands(tri, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
-        const TileSource<D, FAM> src{x + pd.xoff, ld, pd.n, (real)sigma2, th};
-        const int gr = (int)r0 + 2 * (lane & 15);
-        real pr0[D], pr1[D];
-        src.point(gr, pr0); src.point(gr + 1, pr1);
-#pragma unroll
-        for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gc = (int)c0 + tile_i(fi, lane, q);
-                real pc[D];
-                src.point(gc, pc);
-                acc.f[fi][0][q] = -src.value(gr, pr0, gc, pc);
-                acc.f[fi][1][q] = -src.value(gr + 1, pr1, gc, pc);
-            }
     } else {
+        // the wave without a GEMM sub-tile does the forward-solve right-hand side, two rows per lane:
+        // rhs = y_{k+1} - L[k+1, 0:k+1] z_{0:k+1}
+        const real *Lr = S + t0 + 2 * lane;
+        const real *zz = z + pd.yoff;
+        real2_t s0 = {0.0, 0.0}, s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, s3 = {0.0, 0.0};
+        for (int c = 0; c < K2; c += 16) {     // 16 independent column loads in flight per batch
+            real2_t av[16];
 #pragma unroll
-        for (int fi = 0; fi < 8; ++fi)
+            for (int u = 0; u < 16; ++u) av[u] = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + u) * ld);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cl = tile_i(fi, lane, q);
-                const real2_t a = *reinterpret_cast<const real2_t *>(out + cl * ld);
-                acc.f[fi][0][q] = a[0];
-                acc.f[fi][1][q] = a[1];
+            for (int u = 0; u < 16; u += 4) {
+                s0 += av[u] * zz[c + u]; s1 += av[u + 1] * zz[c + u + 1];
+                s2 += av[u + 2] * zz[c + u + 2]; s3 += av[u + 3] * zz[c + u + 3];
             }
-        __builtin_amdgcn_sched_barrier(0);      // keep the tile loads ahead of the staging loads
-        stage_tri_operands(tri, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
-#pragma unroll
-        for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc.f[fi][0][q] = -acc.f[fi][0][q];
-                acc.f[fi][1][q] = -acc.f[fi][1][q];
-            }
+        }
+        const real2_t sum = (s0 + s1) + (s2 + s3);
+        const real2_t yy = *reinterpret_cast<const real2_t *>(y + pd.yoff + t0 + 2 * lane);
+        *reinterpret_cast<real2_t *>(lds + POTRF_RHS + 2 * lane) = yy - sum;
     }
     __syncthreads();
-    if (k > 0) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
-    // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
-    tri_solve_inplace<1>(acc, tri, lane);
-#pragma unroll
-    for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cl = tile_i(fi, lane, q);
-            real2_t o;
-            o[0] = acc.f[fi][0][q];
-            o[1] = acc.f[fi][1][q];
-            *reinterpret_cast<real2_t *>(out + cl * ld) = o;
-        }
+    tile_potrf(Att, ld, lds, ninv + pd.ioff + (int64_t)(k + 1) * (4 * SB * SB), z + pd.yoff + t0, info + pid, k + 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -511,56 +422,40 @@ __global__ __launch_bounds__(1024) void chol_backsolve_kernel(const PatchDesc *_
         for (int i = tid; i < pd.ld; i += 1024) cvec[pd.yoff + i] = cs[i];
 }
 
-template <int D, int FAM, int FUSE>
-static int launch_cholesky_T(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
+int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 {
     // gemm_nt consumes K in groups of 4*PF k-indices; K is always a multiple of TILE here
-    static_assert(TILE % (4 * PF_DIAG) == 0 && TILE % (4 * PF_CHOL) == 0, "prefetch depth must divide TILE/4");
-    PMK_HIP(hipMemsetAsync(m->d_info + p0, 0, sizeof(int32_t) * np, s));
+    static_assert(TILE % (4 * PF_DIAG) == 0 && TILE % (4 * PF_CHOL) == 0 && TILE % (4 * PFJ_CHOL) == 0,
+                  "prefetch depth must divide TILE/4");
+    if (p0 != 0 || np != m->P) { set_error("launch_cholesky: sub-batches are not supported"); return -2; }
+    PMK_HIP(hipMemsetAsync(m->d_info, 0, sizeof(int32_t) * (size_t)np, s));
     pmk_ctx *c = m->ctx;
     c->panel_n = 0;
-    real *ytmp = (real *)m->d_c;      // the weight vector is free until the back substitution: scratch for y - L z
-    static const int dbg_skip = getenv("PMK_DBG_DIAG_SKIP") ? atoi(getenv("PMK_DBG_DIAG_SKIP")) : 0;   // timing experiments only
-    for (int k = 0; k < m->max_nt; ++k) {
-        hipLaunchKernelGGL((chol_diag_kernel<D, FAM, FUSE>), dim3((unsigned)np), dim3(256), 0, s, m->d_desc + p0, (real *)m->d_a,
-                           (real *)m->d_inv, (real *)m->d_y, ytmp, (real *)m->d_z, m->d_info + p0, k, (real *)m->d_x, m->th, m->sigma2, dbg_skip);
-        const int below = m->max_nt - k - 1;
-        if (below > 0) {
-            const bool fine = c->timers >= 2;
-            if (fine) {
-                while ((int)c->panel_ev.size() <= k) {
-                    hipEvent_t a, b;
-                    PMK_HIP(hipEventCreate(&a));
-                    PMK_HIP(hipEventCreate(&b));
-                    c->panel_ev.push_back({a, b});
-                }
-                PMK_HIP(hipEventRecord(c->panel_ev[(size_t)k].first, s));
+    hipLaunchKernelGGL(chol_first_kernel, dim3((unsigned)np), dim3(256), 0, s, m->d_desc, (real *)m->d_a, (real *)m->d_inv,
+                       (const real *)m->d_y, (real *)m->d_z, m->d_info);
+    const bool fine = c->timers >= 2;
+    for (int l = 0; l + 1 < m->max_nt; ++l) {
+        // patches with nt >= max_nt - l are active: a prefix of `order` (sorted by nt, largest first)
+        const int nactive = m->active_prefix[(size_t)(m->max_nt - l)];
+        const int G = m->max_nt - l - 1;                   // block rows below the diagonal, the same for every active patch
+        if (fine) {
+            while ((int)c->panel_ev.size() <= l) {
+                hipEvent_t a, b;
+                PMK_HIP(hipEventCreate(&a));
+                PMK_HIP(hipEventCreate(&b));
+                c->panel_ev.push_back({a, b});
             }
-            // grid.x = block rows below + 1 look-ahead workgroup
-            hipLaunchKernelGGL((chol_panel_kernel<D, FAM, FUSE>), dim3((unsigned)(below + 1), (unsigned)np), dim3(256), 0, s,
-                               m->d_desc + p0, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_y, (real *)m->d_z, ytmp, k, (real *)m->d_x, m->th, m->sigma2);
-            if (fine) {
-                PMK_HIP(hipEventRecord(c->panel_ev[(size_t)k].second, s));
-                c->panel_n = k + 1;
-            }
+            PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].first, s));
+        }
+        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(nactive * G)), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
+                           m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info);
+        if (fine) {
+            PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].second, s));
+            c->panel_n = l + 1;
         }
     }
     PMK_HIP(hipGetLastError());
     return 0;
-}
-
-// fuse != 0: the kernel matrix is evaluated inside the factorisation kernels (no kmat_slab_kernel pass)
-int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, int fuse)
-{
-    if (!fuse) return launch_cholesky_T<1, 0, 0>(m, s, p0, np);
-    const bool s34 = m->th.family == PMK_SPLINE34;
-    switch (m->D) {
-    case 1: return s34 ? launch_cholesky_T<1, PMK_SPLINE34, 1>(m, s, p0, np) : launch_cholesky_T<1, 0, 1>(m, s, p0, np);
-    case 2: return s34 ? launch_cholesky_T<2, PMK_SPLINE34, 1>(m, s, p0, np) : launch_cholesky_T<2, 0, 1>(m, s, p0, np);
-    case 3: return s34 ? launch_cholesky_T<3, PMK_SPLINE34, 1>(m, s, p0, np) : launch_cholesky_T<3, 0, 1>(m, s, p0, np);
-    case 4: return s34 ? launch_cholesky_T<4, PMK_SPLINE34, 1>(m, s, p0, np) : launch_cholesky_T<4, 0, 1>(m, s, p0, np);
-    default: set_error("unsupported input dimension %d", m->D); return -2;
-    }
 }
 
 // -(L[ss])^-1 of every 32 x 32 diagonal block of factors that were loaded from the host (pmk_model_load)
@@ -594,18 +489,21 @@ int launch_ninv_from_slabs(pmk_model *m, hipStream_t s)
     return 0;
 }
 
+// per-device kernel attributes (called by pmk_ctx_create with the context's device current): the back
+// substitution always needs more than the default 64 KB of dynamic LDS
+int set_device_attributes()
+{
+    PMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_backsolve_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
 int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 {
     const size_t fixed = sizeof(real) * (TILE + 10 * SB * (SB + 1));
     const size_t csb = sizeof(real) * (size_t)m->max_nt * TILE;
     const int cs_in_lds = fixed + csb <= 150 * 1024;
     const size_t lds = fixed + (cs_in_lds ? csb : 0);
-    static bool attr_set = false;
-    if (!attr_set) {      // more than the default 64 KB of dynamic LDS
-        PMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chol_backsolve_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(chol_backsolve_kernel, dim3((unsigned)np), dim3(1024), lds, s, m->d_desc + p0, (real *)m->d_a, (real *)m->d_inv,
                        (real *)m->d_z, (real *)m->d_c, cs_in_lds);
     PMK_HIP(hipGetLastError());

@@ -65,13 +65,7 @@ struct pmk_ctx {
     std::vector<Timer> tm;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> panel_ev;   // one pair per panel launch of the last fit
     int panel_n = 0;
-    // the fit runs the patch batch as `fit_groups` independent sub-batches on side streams: the serial,
-    // latency-bound diagonal-block kernel of one group overlaps the MFMA-bound panel kernel of the others
-    int fuse_k1 = 0;        // PMK_FUSE_K1=1 evaluates the kernel matrix inside the factorisation kernels; a tie on MI355X (profiles/r01_fuse_k1.txt), so the separately measurable K1 pass stays the default
-    int fit_groups = 1;     // measured on MI355X (profiles/r01_fit_groups.txt): 1-2 groups tie, more are slower
-    std::vector<hipStream_t> aux;
-    std::vector<hipEvent_t> aux_done;
-    hipEvent_t fork = nullptr;
+    int num_cu = 0;                 // compute units of the device (sizes the persistent prediction grid)
     void tic(const char *name);
     void toc(const char *name);
 };
@@ -92,6 +86,10 @@ struct pmk_model {
     void *d_a = nullptr;                // slabs
     void *d_inv = nullptr;              // -(L[ss])^-1 for every 32 x 32 diagonal block of L
     int32_t *d_info = nullptr;          // per patch
+    // factorisation schedule: patches sorted by tile count (largest first) and, for every threshold t, how many
+    // patches have nt >= t (the active prefix of `order` at launch max_nt - t of the end-aligned schedule)
+    int32_t *d_order = nullptr;
+    std::vector<int32_t> active_prefix;
     int64_t tot_a = 0, tot_x = 0, tot_y = 0, tot_inv = 0;
     bool fitted = false;
     pmk_kernel_desc th{};
@@ -120,14 +118,15 @@ struct pmk_query {
     int32_t *d_item_query = nullptr;    // total
     int32_t *d_sorted_item = nullptr;   // total: sorted position -> item
     int32_t *d_item_pos = nullptr;      // total: item -> sorted position
-    int64_t *d_roff = nullptr;          // P_global+1
+    int64_t *d_roff = nullptr;          // P_global+1 (of the tree attached when the query was created: roff_P)
+    int64_t roff_P = 0;
     std::vector<int64_t> roff;          // host copy
     double *d_u = nullptr, *d_v = nullptr;   // sorted order
     double *d_w = nullptr;                   // reference order (unnormalised), debug
     double *d_yq = nullptr, *d_vq = nullptr; // Nq
     void *d_tmp = nullptr; size_t tmp_bytes = 0;
     void *d_sort_scratch = nullptr; int64_t sort_cap = 0;
-    void *d_tasks = nullptr; int64_t ntasks = 0, strip_grid = 0;   // prediction strip tasks (owned regions)
+    void *d_tasks = nullptr; int64_t ntasks = 0, tasks_cap = 0, strip_grid = 0;   // prediction strip tasks (owned regions)
     bool planned = false;
 };
 
@@ -139,9 +138,10 @@ namespace pmk {
     namespace NS {                                                                                                   \
     int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s,      \
                                    int64_t p0, int64_t np);                                                          \
-    int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, int fuse);                              \
+    int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);                                        \
     int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);                                       \
     int launch_ninv_from_slabs(pmk_model *m, hipStream_t s);                                                         \
+    int set_device_attributes();                                                                                     \
     int build_strip_tasks(pmk_query *q, hipStream_t s);                                                              \
     int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s);                                        \
     }
@@ -152,6 +152,7 @@ PMK_DECLARE_REAL_LAUNCHERS(f32)
 int launch_kernel_matrix_dense(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
                                int64_t mcols, const double *d_zs, int64_t ldz, double *d_K, int64_t ldk,
                                bool symmetric, hipStream_t s);
+int set_plan_attributes();
 int launch_iota(int32_t *d, int64_t n, hipStream_t s);
 int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_plan_fill(pmk_query *q, double radius, double delta, hipStream_t s);

@@ -198,6 +198,28 @@ static int launch_plan_D(pmk_query *q, double radius, double delta, bool fill, h
     return 0;
 }
 
+// the LDS-staged tree of plan_kernel needs up to nn (D + 1) 8 + 4 nn bytes = 90 KB at nn = 2047, D = 4: above the
+// default 64 KB dynamic limit.  Per device, called by pmk_ctx_create with the context's device current.
+template <int D>
+static int set_plan_attributes_D()
+{
+    constexpr int bytes = PLAN_LDS_NODES * (D + 1) * 8 + PLAN_LDS_NODES * 4;
+    PMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(plan_kernel<D, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    PMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(plan_kernel<D, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
+}
+
+int set_plan_attributes()
+{
+    int rc = set_plan_attributes_D<1>();
+    if (!rc) rc = set_plan_attributes_D<2>();
+    if (!rc) rc = set_plan_attributes_D<3>();
+    if (!rc) rc = set_plan_attributes_D<4>();
+    return rc;
+}
+
 static int launch_plan(pmk_query *q, double radius, double delta, bool fill, hipStream_t s)
 {
     int rc = 0;

@@ -164,15 +164,18 @@ int build_strip_tasks(pmk_query *q, hipStream_t s)
             tasks.push_back(t);
         }
     }
-    if (q->d_tasks) { PMK_HIP(hipFree(q->d_tasks)); q->d_tasks = nullptr; }
     q->ntasks = (int64_t)tasks.size();
     if (tasks.empty()) return 0;
-    PMK_HIP(hipMalloc(&q->d_tasks, sizeof(StripTask) * tasks.size()));
+    if (q->tasks_cap < q->ntasks) {          // grow only: repeated plans of one query batch reuse the buffer
+        if (q->d_tasks) { PMK_HIP(hipFree(q->d_tasks)); q->d_tasks = nullptr; }
+        q->tasks_cap = 0;
+        const int64_t cap = q->ntasks + q->ntasks / 8 + 64;
+        PMK_HIP(hipMalloc(&q->d_tasks, sizeof(StripTask) * (size_t)cap));
+        q->tasks_cap = cap;
+    }
     PMK_HIP(hipMemcpyAsync(q->d_tasks, tasks.data(), sizeof(StripTask) * tasks.size(), hipMemcpyHostToDevice, s));
-    PMK_HIP(hipStreamSynchronize(s));
-    hipDeviceProp_t prop;
-    PMK_HIP(hipGetDeviceProperties(&prop, m->ctx->device));
-    const int64_t slots = std::min<int64_t>(q->ntasks, 2 * (int64_t)prop.multiProcessorCount);
+    PMK_HIP(hipStreamSynchronize(s));        // `tasks` is a local
+    const int64_t slots = std::min<int64_t>(q->ntasks, 2 * (int64_t)m->ctx->num_cu);
     const int64_t stride = (int64_t)m->max_nt * TILE * TQ;
     if (m->strip_slots < slots) {
         if (m->d_strip) PMK_HIP(hipFree(m->d_strip));
