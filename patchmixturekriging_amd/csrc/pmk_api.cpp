@@ -217,6 +217,15 @@ int pmk_ctx_timer_ms(pmk_ctx *ctx, const char *stage, double *ms)
         *ms = tot;
         return 0;
     }
+    if (std::strncmp(stage, "step:", 5) == 0) {                    // one factorisation step launch of the last fit
+        const int i = atoi(stage + 5);
+        if (i < 0 || i >= ctx->panel_n) { set_error("no timing recorded for stage '%s'", stage); return -2; }
+        PMK_HIP(hipEventSynchronize(ctx->panel_ev[(size_t)i].second));
+        float f = 0;
+        PMK_HIP(hipEventElapsedTime(&f, ctx->panel_ev[(size_t)i].first, ctx->panel_ev[(size_t)i].second));
+        *ms = f;
+        return 0;
+    }
     for (auto &t : ctx->tm)
         if (t.name == stage && t.valid) {
             PMK_HIP(hipEventSynchronize(t.b));
@@ -686,6 +695,7 @@ int pmk_model_queryinner(pmk_model *m, int64_t patch, const pmk_kernel_desc *th,
     }
     dev_free(q.d_xq); dev_free(q.d_sorted_item); dev_free(q.d_u); dev_free(q.d_v);
     if (q.d_tasks) (void)hipFree(q.d_tasks);
+    if (q.d_sync) (void)hipFree(q.d_sync);
     q.d_item_query = nullptr;
     return rc;
 }
@@ -727,6 +737,7 @@ void pmk_query_destroy(pmk_query *q)
     if (q->d_tmp) (void)hipFree(q->d_tmp);
     if (q->d_sort_scratch) (void)hipFree(q->d_sort_scratch);
     if (q->d_tasks) (void)hipFree(q->d_tasks);
+    if (q->d_sync) (void)hipFree(q->d_sync);
     delete q;
 }
 

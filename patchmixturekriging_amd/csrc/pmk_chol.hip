@@ -170,6 +170,20 @@ __device__ __forceinline__ void tile_potrf(real *__restrict__ Akk, int64_t ld, r
 #undef SBAD
 }
 
+#ifdef PMK_TRACE
+// diagnostic build only (make variant VFLAGS=-DPMK_TRACE=<launch>): wall-clock stamps (100 MHz) of every workgroup of
+// ONE step launch, read back by tools/step_trace.py through pmk_trace_dump; never compiled into libpmk_hip.so
+constexpr int TRACE_WORDS = 8, TRACE_MAX_WG = 8192;
+__device__ unsigned long long g_trace[TRACE_WORDS * TRACE_MAX_WG];
+#define PMK_STAMP(i)                                                                                    \
+    do {                                                                                                \
+        if (launch == PMK_TRACE && threadIdx.x == 0 && blockIdx.x < TRACE_MAX_WG)                       \
+            g_trace[TRACE_WORDS * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime();                 \
+    } while (0)
+#else
+#define PMK_STAMP(i)
+#endif
+
 // first diagonal tile of every patch: nothing to apply, rhs = y_0
 __global__ __launch_bounds__(256, 2) void chol_first_kernel(const PatchDesc *__restrict__ descs, real *__restrict__ A,
                                                             real *__restrict__ ninv, const real *__restrict__ y,
@@ -217,49 +231,76 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
     real *S = A + pd.aoff;
     const int64_t ld = pd.ld;
     const int64_t c0 = (int64_t)k * TILE;
+#ifdef PMK_TRACE
+    if (launch == PMK_TRACE && tid == 0 && blockIdx.x < TRACE_MAX_WG) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_trace[TRACE_WORDS * blockIdx.x + 0] = ((unsigned long long)slot << 32) | (unsigned)bx;
+        g_trace[TRACE_WORDS * blockIdx.x + 1] = ((unsigned long long)hwid << 32) | (xcc & 0xf);
+        g_trace[TRACE_WORDS * blockIdx.x + 6] = 0;
+        g_trace[TRACE_WORDS * blockIdx.x + 7] = __builtin_amdgcn_s_memtime();       // shader clock at the start
+    }
+#endif
+    PMK_STAMP(2);
 
     // ---- block row k + 1 + bx of block column k
     {
         const int64_t r0 = (int64_t)(k + 1 + bx) * TILE + 32 * wave;
+        // a wave whose 32 rows all lie in the identity padding (row index >= n) has nothing to compute: those rows of
+        // L stay zero.  It still takes part in the operand staging and its barrier.  (n = 2000: one wave of the last
+        // block row in every step, 4 % of the MFMA work of a fit.)
+        const bool live = r0 < pd.n;
         real *out = S + r0 + 2 * (lane & 15) + c0 * ld;   // rows of this lane, first column of the block column
         // acc starts as -A[rows, block column k]; the GEMM adds L[rows,0:k] L[k,0:k]^T, so acc = -T.  The tile comes
         // from HBM (first touch): its loads are issued before the operand staging so that the two latencies overlap
         // instead of adding up.
         WaveTile<4, 1> acc;   // I = the 128 columns of block column k, J = 32 rows
+        if (live) {
 #pragma unroll
-        for (int fi = 0; fi < 8; ++fi)
+            for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cl = tile_i(fi, lane, q);
-                const real2_t a = *reinterpret_cast<const real2_t *>(out + cl * ld);
-                acc.f[fi][0][q] = a[0];
-                acc.f[fi][1][q] = a[1];
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = tile_i(fi, lane, q);
+                    const real2_t a = *reinterpret_cast<const real2_t *>(out + cl * ld);
+                    acc.f[fi][0][q] = a[0];
+                    acc.f[fi][1][q] = a[1];
+                }
+        }
         __builtin_amdgcn_sched_barrier(0);      // keep the tile loads ahead of the staging loads
         // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per workgroup
         stage_tri_operands(lds, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
-#pragma unroll
-        for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc.f[fi][0][q] = -acc.f[fi][0][q];
-                acc.f[fi][1][q] = -acc.f[fi][1][q];
-            }
         __syncthreads();
-        if (k > 0) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
-        // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
-        tri_solve_inplace<1>(acc, lds, lane);
+        if (live) {
 #pragma unroll
-        for (int fi = 0; fi < 8; ++fi)
+            for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cl = tile_i(fi, lane, q);
-                real2_t o;
-                o[0] = acc.f[fi][0][q];
-                o[1] = acc.f[fi][1][q];
-                *reinterpret_cast<real2_t *>(out + cl * ld) = o;
-            }
+                for (int q = 0; q < 4; ++q) {
+                    acc.f[fi][0][q] = -acc.f[fi][0][q];
+                    acc.f[fi][1][q] = -acc.f[fi][1][q];
+                }
+            if (k > 0) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
+            // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
+            tri_solve_inplace<1>(acc, lds, lane);
+#pragma unroll
+            for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = tile_i(fi, lane, q);
+                    real2_t o;
+                    o[0] = acc.f[fi][0][q];
+                    o[1] = acc.f[fi][1][q];
+                    *reinterpret_cast<real2_t *>(out + cl * ld) = o;
+                }
+        }
     }
+    PMK_STAMP(3);
+#ifdef PMK_TRACE
+    if (launch == PMK_TRACE && tid == 0 && blockIdx.x < TRACE_MAX_WG)      // shader cycles of wave 0's block-row phase
+        g_trace[TRACE_WORDS * blockIdx.x + 7] = __builtin_amdgcn_s_memtime() - g_trace[TRACE_WORDS * blockIdx.x + 7];
+    if (launch == PMK_TRACE && lane == 0 && blockIdx.x < TRACE_MAX_WG)
+        atomicMax(&g_trace[TRACE_WORDS * blockIdx.x + 6], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
     if (bx != 0) return;
 
     // ================= critical workgroup: look-ahead + potrf of diagonal tile k + 1 =================
@@ -321,7 +362,9 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
         *reinterpret_cast<real2_t *>(lds + POTRF_RHS + 2 * lane) = yy - sum;
     }
     __syncthreads();
+    PMK_STAMP(4);
     tile_potrf(Att, ld, lds, ninv + pd.ioff + (int64_t)(k + 1) * (4 * SB * SB), z + pd.yoff + t0, info + pid, k + 1);
+    PMK_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,6 +500,14 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
     PMK_HIP(hipGetLastError());
     return 0;
 }
+
+#if defined(PMK_TRACE) && !defined(PMK_REAL_F32)
+extern "C" int pmk_trace_dump(unsigned long long *out, int nwords)
+{
+    const size_t want = sizeof(unsigned long long) * (size_t)std::min(nwords, TRACE_WORDS * TRACE_MAX_WG);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), want) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // -(L[ss])^-1 of every 32 x 32 diagonal block of factors that were loaded from the host (pmk_model_load)
 __global__ __launch_bounds__(64) void ninv_from_slab_kernel(const PatchDesc *__restrict__ descs, const real *__restrict__ A,

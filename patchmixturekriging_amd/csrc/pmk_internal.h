@@ -13,7 +13,7 @@ namespace pmk {
 
 constexpr int TILE = 128;       // factorisation tile edge; slabs are padded to a multiple of it
 constexpr int MAX_D = 4;        // input dimension limit (the reference's examples use 1, 2 and 3)
-constexpr int TQ = 128;         // query columns per prediction strip (4 waves x 32)
+constexpr int TQ = 256;         // query columns per prediction strip (8 waves x 32)
 
 void set_error(const char *fmt, ...);
 
@@ -126,7 +126,8 @@ struct pmk_query {
     double *d_yq = nullptr, *d_vq = nullptr; // Nq
     void *d_tmp = nullptr; size_t tmp_bytes = 0;
     void *d_sort_scratch = nullptr; int64_t sort_cap = 0;
-    void *d_tasks = nullptr; int64_t ntasks = 0, tasks_cap = 0, strip_grid = 0;   // prediction strip tasks (owned regions)
+    void *d_tasks = nullptr; int64_t ntasks = 0, tasks_cap = 0, strip_grid = 0;
+    uint32_t *d_sync = nullptr; int64_t sync_cap = 0, nsync = 0, round_base = 0;   // arrival counters of the strips' lock-step groups   // prediction strip tasks (owned regions)
     bool planned = false;
 };
 

@@ -56,16 +56,19 @@ struct WaveTile {
 // register rings: the I operand is shared by the workgroups of a patch / region and comes from L2
 // (depth PFI k-steps), the J operand is this wave's own stream from HBM and needs the deeper ring (PFJ,
 // a multiple of PFI).  K must be a positive multiple of 4*PFJ.
-template <int NPI, int NPJ, int PFI, int PFJ = PFI>
+// NACT < NPI: only the first NACT index pairs of the I dimension are computed (the rest of the tile is known to be
+// zero: identity padding of the last block row).
+template <int NPI, int NPJ, int PFI, int PFJ = PFI, int NACT = NPI>
 __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI,
                                         const real *opJ, int64_t ldJ, int K, int lane)
 {
     static_assert(PFJ % PFI == 0, "the J ring depth must be a multiple of the I ring depth");
-    real2_t ra[PFI][NPI], rb[PFJ][NPJ];
+    static_assert(NACT >= 1 && NACT <= NPI, "active pairs");
+    real2_t ra[PFI][NACT], rb[PFJ][NPJ];
 #pragma unroll
     for (int s = 0; s < PFI; ++s)
 #pragma unroll
-        for (int pi = 0; pi < NPI; ++pi) ra[s][pi] = load_pair(opI + 32 * pi + (int64_t)(4 * s) * ldI, ldI, lane);
+        for (int pi = 0; pi < NACT; ++pi) ra[s][pi] = load_pair(opI + 32 * pi + (int64_t)(4 * s) * ldI, ldI, lane);
 #pragma unroll
     for (int s = 0; s < PFJ; ++s)
 #pragma unroll
@@ -75,7 +78,7 @@ __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, 
         for (int s = 0; s < PFJ; ++s) {
             const int si = s % PFI;
 #pragma unroll
-            for (int pi = 0; pi < NPI; ++pi)
+            for (int pi = 0; pi < NACT; ++pi)
 #pragma unroll
                 for (int ei = 0; ei < 2; ++ei)
 #pragma unroll
@@ -89,7 +92,7 @@ __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, 
             ki = ki < K ? ki : K - 4;
             kj = kj < K ? kj : K - 4;
 #pragma unroll
-            for (int pi = 0; pi < NPI; ++pi) ra[si][pi] = load_pair(opI + 32 * pi + (int64_t)ki * ldI, ldI, lane);
+            for (int pi = 0; pi < NACT; ++pi) ra[si][pi] = load_pair(opI + 32 * pi + (int64_t)ki * ldI, ldI, lane);
 #pragma unroll
             for (int pj = 0; pj < NPJ; ++pj) rb[s][pj] = load_pair_stream(opJ + 32 * pj + (int64_t)kj * ldJ, ldJ, lane);
             // without this fence the scheduler hoists every load of the group to the loop head and doubles the

@@ -5,33 +5,91 @@
 //     V  = L_r^-1 kq             (blocked forward substitution, every product on fp64 MFMA)
 //     v  = clamp(k(xq,xq) - |V|^2, 1e-12, inf)
 // The reference runs one dtrsv per (query, region) and streams the 4 n^2-byte factor each time; here a
-// workgroup owns a strip of TQ = 128 query columns (4 waves x 32 columns, waves independent) and
-// sweeps the block rows of L once for all of them.
+// workgroup owns a strip of TQ = 256 query columns (8 waves x 32 columns: one workgroup per CU, two waves per
+// SIMD) and sweeps the block rows of L once for all of them.
 //
 // Strip task, block row i:  acc(128 x 32) = Kq_i - sum_{j<i} L[i,j] V_j   (gemm_nt, V_j re-read from the
 // wave's strip in global memory, which is stored negated so the MFMA accumulates the subtraction)
 //                           -V_i = -L[ii]^-1 acc                          (tri_solve_inplace: block substitution)
+//
+// HBM traffic.  A strip streams the factor once (n^2/2 elements per TQ columns) and re-reads its own V block rows
+// (n^2/(2*128) elements per column).  The factor is the operand every strip of a region shares: strips of one region
+// that run at the same time on one XCD are kept in LOCK-STEP (a bounded spin on an arrival counter at the head of
+// every block row -- timing only, no data is handed over, so a missed rendezvous costs time, never correctness)
+// and the block row of L is then served to all of them by ONE fetch into that XCD's L2.
+#include <algorithm>
 #include <cstdlib>
+#include <tuple>
 
 #include "pmk_mfma.h"
 
 namespace pmk {
 namespace PMK_NS {
 
-constexpr int PF_PRED = 4;
+#ifndef PMK_PFI_PRED
+#define PMK_PFI_PRED 4
+#endif
+constexpr int PF_PRED = PMK_PFI_PRED;       // I-operand (factor, from L2) prefetch depth in k-steps
 #ifndef PMK_PFJ
 #define PMK_PFJ 4
 #endif
 constexpr int PFJ_PRED = PMK_PFJ;   // J-operand (the wave's own strip columns, HBM) prefetch depth
+constexpr int PRED_WAVES = TQ / 32;
+constexpr int PRED_THREADS = 64 * PRED_WAVES;
+#ifndef PMK_SYNC_TICKS
+#define PMK_SYNC_TICKS 4000         // lock-step rendezvous: give up after 40 us (s_memrealtime ticks of 10 ns)
+#endif
+#ifndef PMK_ROUND_TICKS
+#define PMK_ROUND_TICKS 300000      // round barrier: give up after 3 ms, and then for the rest of the launch
+#endif
+
+#ifdef PMK_TRACE
+// diagnostic build only: rendezvous statistics [0] syncs, [1] timeouts, [2] total wait ticks (10 ns), [3] max wait
+__device__ unsigned long long g_sync_stats[4];
+// phase stamps of block row PMK_TRACE_ROW in round PMK_TRACE_ROUND: [wg][wave][8]
+__device__ unsigned long long g_row_stamp[512 * 40];
+#ifndef PMK_TRACE_ROW
+#define PMK_TRACE_ROW 8
+#endif
+#ifndef PMK_TRACE_ROUND
+#define PMK_TRACE_ROUND 3
+#endif
+#define PMK_PSTAMP(k)                                                                                        \
+    do {                                                                                                     \
+        if (round == PMK_TRACE_ROUND && i == PMK_TRACE_ROW && lane == 0 && blockIdx.x < 64)                   \
+            g_row_stamp[(blockIdx.x * 8 + wave) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();               \
+    } while (0)
+#else
+#define PMK_PSTAMP(k)
+#endif
 
 struct StripTask {
     int32_t region;    // local patch index in the model
     int32_t count;     // valid columns (<= TQ)
     int64_t first;     // first sorted item of the strip
+    int32_t group;     // lock-step group (arrival counter index); -1: alone
+    int32_t gsize;     // strips in the group
 };
 
+// one block row of the strip: acc = Kq_i (in) -> -V_i (out)
+template <int NACT>
+__device__ __forceinline__ void strip_block_row(WaveTile<4, 1> &acc, const real *Li, int64_t ld, const real *V, int i,
+                                                const real *tri, int lane)
+{
+    if (i > 0) {
+        // order this wave's earlier strip stores before its loads of them
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                gemm_nt<4, 1, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
+    }
+#ifdef PMK_TRACE
+    if (i == PMK_TRACE_ROW && lane == 0 && blockIdx.x < 64 && g_row_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 2] != 0)
+        g_row_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
+    tri_solve_inplace<1>(acc, tri, lane);
+}
+
 template <int D, int FAM>
-__global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *__restrict__ descs,
+__global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const PatchDesc *__restrict__ descs,
                                                                const real *__restrict__ x, const real *__restrict__ A,
                                                                const real *__restrict__ inv, const real *__restrict__ cvec,
                                                                const StripTask *__restrict__ tasks, int ntasks,
@@ -39,19 +97,38 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
                                                                const int32_t *__restrict__ item_query,
                                                                const double *__restrict__ xq, real *__restrict__ strips,
                                                                int64_t strip_stride, pmk_kernel_desc th,
+                                                               uint32_t *__restrict__ sync_cnt, int round_base,
                                                                double *__restrict__ u_out, double *__restrict__ v_out)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     real *V = strips + (int64_t)blockIdx.x * strip_stride + 32 * wave;   // this wave's 32 columns, ld = TQ
-    __shared__ real tri[TRI_LDS_DOUBLES];     // TRSM operands of the current block row (shared by the 4 waves)
+    __shared__ real tri[TRI_LDS_DOUBLES];     // TRSM operands of the current block row (shared by the 8 waves)
+    __shared__ real pts[(MAX_D + 1) * TILE];  // the block row's training points (SoA) and weights
+    __shared__ real priv[PRED_WAVES * 8 * 64 * 2];   // lane-private staging of the kernel evaluations (8 slots a lane)
 
     // XCD-aware task order: the workgroups of one XCD take consecutive tasks (= strips of the same
     // region, which stream the same factor L) so that L is fetched into one L2 once per region
     const int nround = (ntasks + (int)gridDim.x - 1) / (int)gridDim.x;
+    bool round_sync = true;       // thread 0 only: dropped for good after one missed round barrier
     for (int round = 0; round < nround; ++round) {
         const int base = round * (int)gridDim.x;
         const int nin = min((int)gridDim.x, ntasks - base);          // tasks of this round
         if ((int)blockIdx.x >= nin) break;
+        if (round > 0 && threadIdx.x == 0) {
+            // round barrier of this XCD's workgroups (speed only, bounded): the strips of a round start together, so
+            // that the per-block-row rendezvous below only has to absorb small drifts.  Every earlier round was full.
+            uint32_t *cnt = sync_cnt + round_base + 8 * (round - 1) + (blockIdx.x & 7);
+            const uint32_t want = ((uint32_t)gridDim.x + 7u - (blockIdx.x & 7)) >> 3;   // workgroups with this id mod 8
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (round_sync) {
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                bool ok;
+                while (!(ok = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) &&
+                       __builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)PMK_ROUND_TICKS)
+                    __builtin_amdgcn_s_sleep(32);
+                round_sync = ok;
+            }
+        }
         const int task = base + xcd_remap(blockIdx.x, nin);
         const StripTask tk = tasks[task];
         const bool active = 32 * wave < tk.count;     // wave-uniform; idle waves still help stage operands
@@ -75,42 +152,82 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
             for (int d = 0; d < D; ++d) q[ej][d] = (real)xq[qi * D + d];
         }
         real mu[2] = {0.0, 0.0}, vs[2] = {0.0, 0.0};
+        // rows of the last block row that are not identity padding, in 32-row pairs (n = 2000: 3 of 4)
+        const int last_pairs = (pd.n - (pd.nt - 1) * TILE + 31) >> 5;
 
         for (int i = 0; i < pd.nt; ++i) {
             __syncthreads();                          // every wave is done with the previous block row's operands
+            PMK_PSTAMP(0);
+            if (threadIdx.x == 0 && tk.group >= 0) {
+                // lock-step rendezvous of the strips that share this factor on this XCD (speed only)
+                uint32_t *cnt = sync_cnt + tk.group;
+                const uint32_t want = (uint32_t)tk.gsize * (uint32_t)(i + 1);
+                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
+                       __builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)PMK_SYNC_TICKS)
+                    __builtin_amdgcn_s_sleep(8);
+#ifdef PMK_TRACE
+                const unsigned long long w = __builtin_amdgcn_s_memrealtime() - t0;
+                atomicAdd(&g_sync_stats[0], 1ull);
+                if (w >= (unsigned long long)PMK_SYNC_TICKS) atomicAdd(&g_sync_stats[1], 1ull);
+                atomicAdd(&g_sync_stats[2], w);
+                atomicMax(&g_sync_stats[3], w);
+#endif
+            }
             stage_tri_operands(tri, S + (int64_t)i * TILE + (int64_t)i * TILE * ld, ld, inv + pd.ioff + (int64_t)i * 4096,
-                               threadIdx.x, 256);
+                               threadIdx.x, PRED_THREADS);
+            // the block row's training points and weights, the same for every lane of the workgroup
+            if (threadIdx.x < TILE) {
+                const int row = i * TILE + threadIdx.x;
+#pragma unroll
+                for (int d = 0; d < D; ++d) pts[d * TILE + threadIdx.x] = xs[(int64_t)d * ld + row];
+                pts[D * TILE + threadIdx.x] = cr[row];
+            }
             __syncthreads();
+            PMK_PSTAMP(1);
             if (!active) continue;
             WaveTile<4, 1> acc;
-            // ---- Kq tile for block row i (query is the first kernel argument, mixtureGP.jl:304)
+            // ---- Kq tile for block row i (query is the first kernel argument, mixtureGP.jl:304), 32 rows at a time in a
+            //      ROLLED loop whose results pass through a lane-private LDS slot: fully unrolled, the 64 evaluations of a
+            //      tile and the accumulator they fill were allocated hundreds of spilled registers (scratch traffic was a
+            //      quarter of this kernel's HBM bytes) and 3 k instructions of code per block row
+            real2_t *mine = reinterpret_cast<real2_t *>(priv) + (wave * 8) * 64 + lane;
 #pragma unroll
-            for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int row = i * TILE + tile_i(fi, lane, qq);
+            for (int pi = 0; pi < 4; ++pi) {
+#pragma clang loop unroll_count(2)
+                for (int sl = 0; sl < 8; ++sl) {
+                    const int r = 32 * pi + 2 * frag_irow(lane >> 4, sl >> 1) + (sl & 1);     // row within the block row
                     real xr[D];
 #pragma unroll
-                    for (int d = 0; d < D; ++d) xr[d] = xs[(int64_t)d * ld + row];
-                    const real cw = cr[row];
+                    for (int d = 0; d < D; ++d) xr[d] = pts[d * TILE + r];
+                    const real cw = pts[D * TILE + r];
                     // padding rows carry coordinates of 1e300 (pack_soa): a compactly supported profile is
-                    // exactly 0 there, so the Spline34 instantiation needs no bounds test in its unrolled tile
-                    const bool inside = (FAM == PMK_SPLINE34) || row < pd.n;
-#pragma unroll
-                    for (int ej = 0; ej < 2; ++ej) {
-                        const real kv = inside ? kern_eval<D, FAM, real>(th, q[ej], xr) : 0.0;
-                        acc.f[fi][ej][qq] = kv;
-                        mu[ej] += kv * cw;
-                    }
+                    // exactly 0 there, so the Spline34 instantiation needs no bounds test
+                    const bool inside = (FAM == PMK_SPLINE34) || i * TILE + r < pd.n;
+                    real2_t kv;
+                    kv[0] = inside ? kern_eval<D, FAM, real>(th, q[0], xr) : (real)0;
+                    kv[1] = inside ? kern_eval<D, FAM, real>(th, q[1], xr) : (real)0;
+                    mu[0] += kv[0] * cw;
+                    mu[1] += kv[1] * cw;
+                    mine[sl * 64] = kv;
                 }
-            // ---- acc -= L[i, 0:i] V_0:i   (the strip holds -V)
-            if (i > 0) {
-                // order this wave's earlier strip stores before its loads of them
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                gemm_nt<4, 1, PF_PRED, PFJ_PRED>(acc, S + (int64_t)i * TILE, ld, V, TQ, i * TILE, lane);
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+                    const real2_t kv = mine[sl * 64];
+                    acc.f[2 * pi + (sl & 1)][0][sl >> 1] = kv[0];
+                    acc.f[2 * pi + (sl & 1)][1][sl >> 1] = kv[1];
+                }
             }
-            // ---- acc <- -V_i = -L[ii]^-1 acc   (block substitution; the strip wants -V anyway)
-            tri_solve_inplace<1>(acc, tri, lane);
+            PMK_PSTAMP(2);
+            // ---- acc -= L[i, 0:i] V_0:i  (the strip holds -V), then acc <- -V_i = -L[ii]^-1 acc (block substitution;
+            //      the strip wants -V anyway).  Padding rows of the last block row are zero and stay zero: skip them.
+            const real *Li = S + (int64_t)i * TILE;
+            if (i + 1 == pd.nt && last_pairs == 3) strip_block_row<3>(acc, Li, ld, V, i, tri, lane);
+            else if (i + 1 == pd.nt && last_pairs == 2) strip_block_row<2>(acc, Li, ld, V, i, tri, lane);
+            else if (i + 1 == pd.nt && last_pairs == 1) strip_block_row<1>(acc, Li, ld, V, i, tri, lane);
+            else strip_block_row<4>(acc, Li, ld, V, i, tri, lane);
+            PMK_PSTAMP(4);
 #pragma unroll
             for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
@@ -118,17 +235,20 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
 #pragma unroll
                     for (int ej = 0; ej < 2; ++ej) vs[ej] += acc.f[fi][ej][qq] * acc.f[fi][ej][qq];
             if (i + 1 < pd.nt) {
+                int srow = tile_i(0, lane, 0);
+                asm volatile("" : "+v"(srow));
 #pragma unroll
                 for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
-                        const int row = i * TILE + tile_i(fi, lane, qq);
+                        const int row = i * TILE + srow + (tile_i(fi, 0, qq) - tile_i(0, 0, 0));
                         real2_t o;
                         o[0] = acc.f[fi][0][qq];
                         o[1] = acc.f[fi][1][qq];
                         __builtin_nontemporal_store(o, reinterpret_cast<real2_t *>(V + (int64_t)row * TQ + 2 * (lane & 15)));
                     }
             }
+            PMK_PSTAMP(5);
         }
         // ---- reduce over the four lane groups that share a column, then write (u, v)
 #pragma unroll
@@ -149,6 +269,27 @@ __global__ __launch_bounds__(256, 2) void predict_strip_kernel(const PatchDesc *
     }
 }
 
+#if defined(PMK_TRACE) && !defined(PMK_REAL_F32)
+extern "C" int pmk_trace_sync_stats(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sync_stats), sizeof(unsigned long long) * 4) != hipSuccess) return -1;
+    if (reset == 2) return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_row_stamp), sizeof(unsigned long long) * 512 * 40) == hipSuccess ? 0 : -1;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_sync_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+// the XCD that xcd_remap() gives logical position p of a round of nin workgroups
+static int xcd_of_position(int p, int nin)
+{
+    const int q = nin >> 3, r = nin & 7;
+    const int big = r * (q + 1);
+    return p < big ? p / (q + 1) : r + (q ? (p - big) / q : 0);
+}
+
 // strip tasks for the regions this model owns (host side, after the plan's region offsets are known)
 int build_strip_tasks(pmk_query *q, hipStream_t s)
 {
@@ -156,16 +297,49 @@ int build_strip_tasks(pmk_query *q, hipStream_t s)
     std::vector<StripTask> tasks;
     for (int64_t r = 0; r < m->P; ++r) {
         const int64_t b = q->roff[m->leaf_base + r], e = q->roff[m->leaf_base + r + 1];
-        for (int64_t f = b; f < e; f += TQ) {
+        if (e <= b) continue;
+        // the region's items are dealt evenly over its strips (not TQ, TQ, ..., remainder): strips of one region then
+        // take the same time, which is what keeps them in lock-step
+#ifdef PMK_HALF_STRIPS      /* diagnostic: only waves 0-3 get columns -> one active wave per SIMD */
+        const int64_t nstrips = (e - b + 127) / 128, w = (e - b + nstrips - 1) / nstrips;
+#else
+        const int64_t nstrips = (e - b + TQ - 1) / TQ, w = (e - b + nstrips - 1) / nstrips;
+#endif
+        for (int64_t f = b; f < e; f += w) {
             StripTask t;
             t.region = (int32_t)r;
-            t.count = (int32_t)((e - f) < TQ ? (e - f) : TQ);
+            t.count = (int32_t)((e - f) < w ? (e - f) : w);
             t.first = f;
+            t.group = -1;
+            t.gsize = 1;
             tasks.push_back(t);
         }
     }
     q->ntasks = (int64_t)tasks.size();
+    q->nsync = 0;
     if (tasks.empty()) return 0;
+    const int64_t slots = std::min<int64_t>(q->ntasks, (int64_t)m->ctx->num_cu);     // one 8-wave workgroup per CU
+    // lock-step groups: consecutive tasks of one round that land on one XCD and stream the same factor
+    {
+        int64_t g0 = 0;
+        auto key = [&](int64_t t) {
+            const int64_t round = t / slots, p = t - round * slots;
+            const int nin = (int)std::min<int64_t>(slots, q->ntasks - round * slots);
+            return std::make_tuple(round, (int64_t)xcd_of_position((int)p, nin), (int64_t)tasks[(size_t)t].region);
+        };
+        for (int64_t t = 1; t <= q->ntasks; ++t) {
+            if (t == q->ntasks || key(t) != key(g0)) {
+                if (t - g0 > 1) {
+                    for (int64_t u = g0; u < t; ++u) {
+                        tasks[(size_t)u].group = (int32_t)q->nsync;
+                        tasks[(size_t)u].gsize = (int32_t)(t - g0);
+                    }
+                    ++q->nsync;
+                }
+                g0 = t;
+            }
+        }
+    }
     if (q->tasks_cap < q->ntasks) {          // grow only: repeated plans of one query batch reuse the buffer
         if (q->d_tasks) { PMK_HIP(hipFree(q->d_tasks)); q->d_tasks = nullptr; }
         q->tasks_cap = 0;
@@ -173,9 +347,18 @@ int build_strip_tasks(pmk_query *q, hipStream_t s)
         PMK_HIP(hipMalloc(&q->d_tasks, sizeof(StripTask) * (size_t)cap));
         q->tasks_cap = cap;
     }
+    // arrival counters: one per lock-step group, then one per (round, XCD) for the round barrier
+    q->round_base = q->nsync;
+    q->nsync += 8 * ((q->ntasks + slots - 1) / slots);
+    if (q->sync_cap < q->nsync) {
+        if (q->d_sync) { PMK_HIP(hipFree(q->d_sync)); q->d_sync = nullptr; }
+        q->sync_cap = 0;
+        const int64_t cap = q->nsync + q->nsync / 8 + 64;
+        PMK_HIP(hipMalloc((void **)&q->d_sync, sizeof(uint32_t) * (size_t)cap));
+        q->sync_cap = cap;
+    }
     PMK_HIP(hipMemcpyAsync(q->d_tasks, tasks.data(), sizeof(StripTask) * tasks.size(), hipMemcpyHostToDevice, s));
     PMK_HIP(hipStreamSynchronize(s));        // `tasks` is a local
-    const int64_t slots = std::min<int64_t>(q->ntasks, 2 * (int64_t)m->ctx->num_cu);
     const int64_t stride = (int64_t)m->max_nt * TILE * TQ;
     if (m->strip_slots < slots) {
         if (m->d_strip) PMK_HIP(hipFree(m->d_strip));
@@ -194,18 +377,19 @@ int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s)
     if (q->ntasks == 0) return 0;
     const int64_t stride = (int64_t)m->max_nt * TILE * TQ;
     const StripTask *d_tasks = reinterpret_cast<const StripTask *>(q->d_tasks);
+    if (q->nsync > 0) PMK_HIP(hipMemsetAsync(q->d_sync, 0, sizeof(uint32_t) * (size_t)q->nsync, s));
     const bool s34 = th.family == PMK_SPLINE34;
     switch (m->D) {
 #define PMK_CASE(DD)                                                                                                   \
     case DD:                                                                                                           \
         if (s34)                                                                                                       \
-            hipLaunchKernelGGL((predict_strip_kernel<DD, PMK_SPLINE34>), dim3((unsigned)q->strip_grid), dim3(256), 0, s, \
+            hipLaunchKernelGGL((predict_strip_kernel<DD, PMK_SPLINE34>), dim3((unsigned)q->strip_grid), dim3(PRED_THREADS), 0, s, \
                                m->d_desc, (real *)m->d_x, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
-                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_u, q->d_v);                       \
+                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->d_u, q->d_v);  \
         else                                                                                                           \
-            hipLaunchKernelGGL((predict_strip_kernel<DD, 0>), dim3((unsigned)q->strip_grid), dim3(256), 0, s,           \
+            hipLaunchKernelGGL((predict_strip_kernel<DD, 0>), dim3((unsigned)q->strip_grid), dim3(PRED_THREADS), 0, s,  \
                                m->d_desc, (real *)m->d_x, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
-                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_u, q->d_v);                       \
+                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->d_u, q->d_v);  \
         break;
         PMK_CASE(1) PMK_CASE(2) PMK_CASE(3) PMK_CASE(4)
 #undef PMK_CASE

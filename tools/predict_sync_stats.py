@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""rendezvous statistics of the prediction strips (diagnostic variant build):
+    make -C patchmixturekriging_amd/csrc variant VFLAGS=-DPMK_TRACE=7
+    PMK_LIB=patchmixturekriging_amd/csrc/libpmk_hip_b.so python tools/predict_sync_stats.py [nq]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import patchmixturekriging_amd as pmk  # noqa: E402
+
+
+def main():
+    nq = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+    P, n, levels = 256, 2000, 9
+    rng = np.random.Generator(np.random.PCG64(25))
+    N = P * n
+    X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+    y = np.sin(X[:, 0]) * np.cos(0.3 * X[:, 1])
+    root, Xp, Xi = pmk.setuppartition(X, levels, device=True)
+    ctx = pmk.default_context()
+    model = pmk.DeviceModel(Xp, [y[i] for i in Xi])
+    th = pmk.Spline34KernelType(1 / 15)
+    model.fit(th, 1e-5)
+    model.set_bsp(root, 0)
+    radius = 0.1 * np.sqrt(200.0 / P)
+    Xq = np.stack([rng.uniform(-5, 5, nq), rng.uniform(-10, 10, nq)], 1)
+    q = pmk.DeviceQuery(model, Xq)
+    total = q.plan(radius, 1e-5)
+    L = ctx.L
+    st = np.zeros(4, dtype=np.uint64)
+    for rep in range(3):
+        L.pmk_trace_sync_stats(st.ctypes.data_as(C.c_void_p), 1)
+        ctx.synchronize()
+        t = time.perf_counter()
+        q.items(th)
+        ctx.synchronize()
+        dt = time.perf_counter() - t
+        L.pmk_trace_sync_stats(st.ctypes.data_as(C.c_void_p), 1)
+        print("items %.1f ms for %d pairs: %d rendezvous, %d timeouts, mean wait %.2f us, max %.1f us"
+              % (dt * 1e3, total, st[0], st[1], st[2] / max(int(st[0]), 1) / 100.0, st[3] / 100.0))
+    buf = np.zeros(512 * 40, dtype=np.uint64)
+    L.pmk_trace_sync_stats(buf.ctypes.data_as(C.c_void_p), 2)
+    t = buf[:64 * 8 * 8].reshape(64, 8, 8).astype(np.float64) / 100.0          # [wg][wave][stamp] in us
+    ok = t[:, :, 5].min(axis=1) > 0
+    t = t[ok]
+    print("phase timeline of one block row (traced row/round are compile-time), %d workgroups, us:" % len(t))
+    names = ["rendezvous+staging", "kernel tile (VALU)", "GEMM", "TRSM", "norms + V store"]
+    for k, nm in enumerate(names):
+        d = t[:, :, k + 1] - t[:, :, k]
+        print("  %-20s med %.1f  p10 %.1f  p90 %.1f" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+    tot = t[:, :, 5] - t[:, :, 0]
+    print("  %-20s med %.1f" % ("whole block row", np.median(tot)))
+    w0 = t[:, :, 5].max(axis=1) - t[:, :, 5].min(axis=1)
+    print("  spread of the 8 waves' finish times within a workgroup: med %.1f us" % np.median(w0))
+    for w in range(8):
+        print("   wave %d: GEMM med %.1f us, ends at +%.1f us" % (w, np.median(t[:, w, 3] - t[:, w, 2]), np.median(t[:, w, 5] - t[:, :, 0].min(axis=1))))
+
+
+if __name__ == "__main__":
+    main()
