@@ -178,8 +178,8 @@ int  pmk_query_region_offsets(pmk_query *q, int64_t *region_offsets);
 /* stage 2: queryinner! (mixtureGP.jl:296-316) for every owned item: u = kq.c,
  * v = clamp(k(x,x) - |L^-1 kq|^2, 1e-12, inf).  Enqueues only. */
 int  pmk_query_items(pmk_query *q, const pmk_kernel_desc *th);
-/* device pointers of the per-item results in sorted order (length total_items each); a
- * multi-GPU caller all-gathers the owned segments into them between stage 2 and 3 */
+/* device pointers of the per-item results in sorted order (length total_items each): where a multi-GPU caller that
+ * drives the exchange itself deposits the (u, v) it gets back from the leaf owners between stage 2 and 3 */
 int  pmk_query_item_buffers(pmk_query *q, void **u_dev, void **v_dev);
 /* ---- multi-GPU, queries sharded over ranks: a rank plans only its own queries against the
  * global tree, sends the (point, region) requests of every sorted-list segment to the rank that owns those leaves,
@@ -192,6 +192,24 @@ int  pmk_query_create_items(pmk_model *m, int64_t n, const double *xq, const int
 /* (u, v) of all items in item order (the order given to pmk_query_create_items; reference order for a planned
  * query) -> DEVICE arrays of length total_items (either may be NULL).  Enqueues. */
 int  pmk_query_export_results(pmk_query *q, double *u_dev, double *v_dev);
+/* ---- multi-GPU inside the library: an RCCL communicator (one rank per GPU, xGMI) owned by a context --------------
+ * rank 0 calls pmk_comm_unique_id and ships the 128 bytes to the other ranks by any host channel (MPI.jl, a file,
+ * torch.distributed ...); every rank then calls pmk_comm_create (collective).  RCCL is bound at run time. */
+#define PMK_COMM_ID_BYTES 128
+typedef struct pmk_comm pmk_comm;
+int  pmk_comm_unique_id(void *id_out);
+int  pmk_comm_create(pmk_ctx *ctx, int rank, int world, const void *id, pmk_comm **out);
+int  pmk_comm_rank(const pmk_comm *comm);
+int  pmk_comm_size(const pmk_comm *comm);
+void pmk_comm_destroy(pmk_comm *comm);
+/* (first, count) of every rank's segment of a region-sorted item list (rank r owns leaves [r P/world, (r+1) P/world)) */
+int  pmk_shard_segments(const int64_t *region_offsets, int64_t P_global, int world, int64_t *first, int64_t *count);
+/* one predict step of a model whose leaves and queries are sharded over the communicator (collective):
+ * querymixtureGP! (mixtureGP.jl:159-294) for THIS rank's queries = plan -> requests to the leaf owners (grouped
+ * ncclSend/ncclRecv) -> queryinner! for everything received -> (u, v) back -> mixture.  Enqueues on the context's
+ * stream after the plan; results with pmk_query_fetch.  total_items (may be NULL): this rank's item count. */
+int  pmk_query_predict_sharded(pmk_query *q, pmk_comm *comm, const pmk_kernel_desc *th,
+                               const pmk_kernel_desc *weight_th, double radius, double delta, int64_t *total_items);
 /* stage 3: mixture weights and blend (mixtureGP.jl:224-272) for queries [q0, q1).  Enqueues. */
 int  pmk_query_mix(pmk_query *q, const pmk_kernel_desc *weight_th, int64_t q0, int64_t q1);
 /* blocks; Yq, Vq [Nq] (either may be NULL) */

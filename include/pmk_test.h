@@ -24,6 +24,10 @@ int pmk_selftest_trisolve(pmk_ctx *ctx, const double *L, const double *ninv, con
 /* sustained fp64 MFMA rate of the device in TFLOP/s (register-resident loop, all CUs) */
 int pmk_selftest_mfma_peak(pmk_ctx *ctx, double *tflops);
 
+/* make pmk_query_predict_sharded run its whole request / response exchange even when the communicator has one rank
+ * (the rank then sends to itself through RCCL): the only way to drive that path on a one-GPU box */
+int pmk_test_comm_force_exchange(pmk_comm *comm, int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ libpmk_hip.so (hand-written HIP for gfx950) through the C ABI of include/pmk.h; 
 fallback -- without the library the operators raise.
 """
 from ._lib import PmkError, build, lib                                              # noqa: F401
-from .context import Context, default_context, set_device                            # noqa: F401
+from .context import Comm, Context, comm_unique_id, default_context, set_device, shard_segments                            # noqa: F401
 from .kernels import (BrownianBridge10, BrownianBridge1eps, BrownianBridge20,        # noqa: F401
                       BrownianBridge2eps, BrownianBridgeKernelType, BrownianBridgeSemiInfDomain,
                       GaussianKernel1DType, ModulatedSqExpKernelType, RationalQuadraticKernelType,

@@ -91,6 +91,13 @@ SIGNATURES = {
     "pmk_query_items": (C.c_int, [_vp, _kp]),
     "pmk_query_item_buffers": (C.c_int, [_vp, _vpp, _vpp]),
     "pmk_query_mix": (C.c_int, [_vp, _kp, C.c_int64, C.c_int64]),
+    "pmk_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pmk_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_void_p, _vpp]),
+    "pmk_comm_rank": (C.c_int, [_vp]),
+    "pmk_comm_size": (C.c_int, [_vp]),
+    "pmk_comm_destroy": (None, [_vp]),
+    "pmk_shard_segments": (C.c_int, [_ip, C.c_int64, C.c_int, _ip, _ip]),
+    "pmk_query_predict_sharded": (C.c_int, [_vp, _vp, _kp, _kp, C.c_double, C.c_double, _ip]),
     "pmk_query_fetch": (C.c_int, [_vp, _dp, _dp]),
     "pmk_query_debug": (C.c_int, [_vp, _ip, _ip, _ip, _dp, _dp, _dp, _dp]),
     "pmk_query_destroy": (None, [_vp]),
@@ -100,6 +107,7 @@ SIGNATURES = {
     "pmk_selftest_gemm": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "pmk_selftest_trisolve": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "pmk_selftest_mfma_peak": (C.c_int, [_vp, _dp]),
+    "pmk_test_comm_force_exchange": (C.c_int, [_vp, C.c_int]),
 }
 
 

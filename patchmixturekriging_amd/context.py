@@ -35,6 +35,50 @@ class Context:
             self.h = None
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """pmk_comm_unique_id: 128 opaque bytes made by ONE rank, to be shipped to the others by any host channel"""
+    L = _lib.lib()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _lib.check(L.pmk_comm_unique_id(buf), "pmk_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """pmk_comm: the library's own RCCL communicator (one rank per GPU); creation is collective"""
+
+    def __init__(self, ctx, rank, world, unique_id):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("the communicator id is %d bytes" % COMM_ID_BYTES)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        _lib.check(ctx.L.pmk_comm_create(ctx.h, self.rank, self.world, buf, C.byref(h)), "pmk_comm_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.pmk_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def shard_segments(region_offsets, world):
+    """pmk_shard_segments: (first, count) of every rank's segment of a region-sorted item list"""
+    import numpy as np
+    L = _lib.lib()
+    off = np.ascontiguousarray(region_offsets, dtype=np.int64)
+    first, count = np.empty(world, dtype=np.int64), np.empty(world, dtype=np.int64)
+    ip = C.POINTER(C.c_int64)
+    _lib.check(L.pmk_shard_segments(off.ctypes.data_as(ip), len(off) - 1, int(world), first.ctypes.data_as(ip),
+                                    count.ctypes.data_as(ip)), "pmk_shard_segments")
+    return list(zip(first.tolist(), count.tolist()))
+
+
 def set_device(device):
     """choose the GPU of the default context (before first use)"""
     global _DEVICE, _CTX

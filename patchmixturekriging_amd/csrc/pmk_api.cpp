@@ -733,7 +733,7 @@ void pmk_query_destroy(pmk_query *q)
     dev_free(q->d_xq); dev_free(q->d_home); dev_free(q->d_cnt); dev_free(q->d_qoff);
     dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
     dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_roff);
-    dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w); dev_free(q->d_yq); dev_free(q->d_vq);
+    dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w); dev_free(q->d_yq); dev_free(q->d_vq); dev_free(q->d_flag);
     if (q->d_tmp) (void)hipFree(q->d_tmp);
     if (q->d_sort_scratch) (void)hipFree(q->d_sort_scratch);
     if (q->d_tasks) (void)hipFree(q->d_tasks);
@@ -741,8 +741,75 @@ void pmk_query_destroy(pmk_query *q)
     delete q;
 }
 
+}  // extern "C"
+
+namespace pmk {
+
+// per-query-point buffers for up to Nq points, grow only
+int query_reserve(pmk_query *q, int64_t Nq)
+{
+    pmk_model *m = q->m;
+    if (Nq <= q->nq_cap) return 0;
+    const bool regrow = q->nq_cap > 0;
+    dev_free(q->d_xq); dev_free(q->d_home); dev_free(q->d_cnt); dev_free(q->d_qoff); dev_free(q->d_yq); dev_free(q->d_vq);
+    q->nq_cap = 0;
+    const int64_t cap = Nq + (regrow ? Nq / 8 : 0);
+    int rc = 0;
+    rc |= dev_alloc(&q->d_xq, cap * m->D);
+    rc |= dev_alloc(&q->d_home, cap);
+    rc |= dev_alloc(&q->d_cnt, cap + 1);
+    rc |= dev_alloc(&q->d_qoff, cap + 1);
+    rc |= dev_alloc(&q->d_yq, cap);
+    rc |= dev_alloc(&q->d_vq, cap);
+    if (rc) return -100;
+    q->nq_cap = cap;
+    return 0;
+}
+
+int grow_item_buffers(pmk_query *q, int64_t total);
+
+// (re)load a query object with n explicit (point, region) items, one per point (host or device pointers): what
+// pmk_query_create_items does after allocating; reuses the object's buffers.  Blocks (region offsets come back).
+int query_set_items(pmk_query *q, int64_t n, const double *xq, const int32_t *region)
+{
+    pmk_model *m = q->m;
+    pmk_ctx *c = m->ctx;
+    hipStream_t s = c->stream;
+    int rc;
+    if ((rc = query_reserve(q, n))) return rc;
+    q->Nq = n;
+    q->total = n;
+    q->planned = false;
+    q->roff.assign((size_t)(m->P_global + 1), 0);
+    q->ntasks = 0;
+    if (n > 0) {
+        int bad = 0;
+        if ((rc = grow_item_buffers(q, n))) return rc;
+        if (!q->d_flag && dev_alloc(&q->d_flag, 1)) return -100;
+        hipError_t e = hipMemcpyAsync(q->d_xq, xq, sizeof(double) * (size_t)(n * m->D), hipMemcpyDefault, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(q->d_item_region, region, sizeof(int32_t) * (size_t)n, hipMemcpyDefault, s);
+        if (e == hipSuccess) e = hipMemsetAsync(q->d_flag, 0, sizeof(int), s);
+        if (e == hipSuccess) rc = launch_explicit_items(q, q->d_flag, s);
+        if (e == hipSuccess && !rc) rc = launch_sort_items(q, s);
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(&bad, q->d_flag, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && !rc)
+            e = hipMemcpyAsync(q->roff.data(), q->d_roff, sizeof(int64_t) * q->roff.size(), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_error("query_set_items: %s", hipGetErrorString(e)); return -100; }
+        if (rc) return rc;
+        if (bad) {
+            set_error("pmk_query_create_items: a region is outside this model's leaves [%lld, %lld)",
+                      (long long)m->leaf_base, (long long)(m->leaf_base + m->P));
+            return -3;
+        }
+        if ((rc = PMK_BY_DTYPE(m, build_strip_tasks(q, s)))) return rc;
+    }
+    q->planned = true;
+    return 0;
+}
+
 // per-item buffers, grow only: repeated plans of one query batch reuse them
-static int grow_item_buffers(pmk_query *q, int64_t total)
+int grow_item_buffers(pmk_query *q, int64_t total)
 {
     if (total <= q->item_cap) return 0;
     dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
@@ -763,6 +830,10 @@ static int grow_item_buffers(pmk_query *q, int64_t total)
     return 0;
 }
 
+}  // namespace pmk
+
+extern "C" {
+
 int pmk_query_create(pmk_model *m, int64_t Nq, const double *Xq, pmk_query **out)
 {
     if (!out) { set_error("pmk_query_create: out is NULL"); return -4; }
@@ -774,14 +845,8 @@ int pmk_query_create(pmk_model *m, int64_t Nq, const double *Xq, pmk_query **out
     pmk_query *q = new (std::nothrow) pmk_query();
     if (!q) { set_error("out of memory"); return -100; }
     q->m = m; q->Nq = Nq; q->roff_P = m->P_global;
-    int rc = 0;
-    rc |= dev_alloc(&q->d_xq, Nq * m->D);
-    rc |= dev_alloc(&q->d_home, Nq);
-    rc |= dev_alloc(&q->d_cnt, Nq + 1);
-    rc |= dev_alloc(&q->d_qoff, Nq + 1);
+    int rc = query_reserve(q, std::max<int64_t>(Nq, 1));
     rc |= dev_alloc(&q->d_roff, m->P_global + 1);
-    rc |= dev_alloc(&q->d_yq, Nq);
-    rc |= dev_alloc(&q->d_vq, Nq);
     if (rc) { pmk_query_destroy(q); return -100; }
     if (Nq > 0) PMK_HIP(hipMemcpy(q->d_xq, Xq, sizeof(double) * (size_t)(Nq * m->D), hipMemcpyDefault));
     *out = q;
@@ -792,40 +857,11 @@ int pmk_query_create_items(pmk_model *m, int64_t n, const double *xq, const int3
 {
     if (!out) { set_error("pmk_query_create_items: out is NULL"); return -4; }
     *out = nullptr;
-    if (n > 0 && !region) { set_error("pmk_query_create_items: region is NULL"); return -2; }
+    if (n > 0 && (!region || !xq)) { set_error("pmk_query_create_items: NULL points or regions"); return -2; }
     pmk_query *q = nullptr;
-    int rc = pmk_query_create(m, n, xq, &q);
+    int rc = pmk_query_create(m, 0, nullptr, &q);
     if (rc) return rc;
-    pmk_ctx *c = m->ctx;
-    hipStream_t s = c->stream;
-    q->total = n;
-    q->roff.assign((size_t)(m->P_global + 1), 0);
-    if (n > 0) {
-        int *d_bad = nullptr;
-        int bad = 0;
-        if ((rc = grow_item_buffers(q, n)) || (rc = dev_alloc(&d_bad, 1))) { pmk_query_destroy(q); return -100; }
-        hipError_t e = hipMemcpyAsync(q->d_item_region, region, sizeof(int32_t) * (size_t)n, hipMemcpyDefault, s);
-        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), s);
-        if (e == hipSuccess) rc = launch_explicit_items(q, d_bad, s);
-        if (e == hipSuccess && !rc) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess && !rc) e = hipStreamSynchronize(s);
-        dev_free(d_bad);
-        if (e != hipSuccess) { set_error("pmk_query_create_items: %s", hipGetErrorString(e)); rc = -100; }
-        if (!rc && bad) {
-            set_error("pmk_query_create_items: a region is outside this model's leaves [%lld, %lld)",
-                      (long long)m->leaf_base, (long long)(m->leaf_base + m->P));
-            rc = -3;
-        }
-        if (!rc) rc = launch_sort_items(q, s);
-        if (!rc) {
-            e = hipMemcpyAsync(q->roff.data(), q->d_roff, sizeof(int64_t) * q->roff.size(), hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (e != hipSuccess) { set_error("pmk_query_create_items: %s", hipGetErrorString(e)); rc = -100; }
-        }
-        if (!rc) rc = PMK_BY_DTYPE(m, build_strip_tasks(q, s));
-        if (rc) { pmk_query_destroy(q); return rc; }
-    }
-    q->planned = true;
+    if ((rc = query_set_items(q, n, xq, region))) { pmk_query_destroy(q); return rc; }
     *out = q;
     return 0;
 }

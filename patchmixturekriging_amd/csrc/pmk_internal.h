@@ -107,6 +107,8 @@ struct pmk_model {
 struct pmk_query {
     pmk_model *m = nullptr;
     int64_t Nq = 0;
+    int64_t nq_cap = 0;             // capacity of the per-point buffers below (grow only)
+    int *d_flag = nullptr;          // device scratch flag (region range check of explicit items)
     double *d_xq = nullptr;         // point-major D x Nq
     int32_t *d_home = nullptr;      // Nq
     int32_t *d_cnt = nullptr;       // Nq : items per query (neighbours + 1)
@@ -155,12 +157,15 @@ int launch_kernel_matrix_dense(const pmk_kernel_desc &th, int D, int64_t n, cons
                                bool symmetric, hipStream_t s);
 int set_plan_attributes();
 int launch_iota(int32_t *d, int64_t n, hipStream_t s);
+int query_reserve(pmk_query *q, int64_t Nq);
+int query_set_items(pmk_query *q, int64_t n, const double *xq, const int32_t *region);
 int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_plan_fill(pmk_query *q, double radius, double delta, hipStream_t s);
 int launch_sort_items(pmk_query *q, hipStream_t s);
 int launch_mix(pmk_query *q, const pmk_kernel_desc &wth, int64_t q0, int64_t q1, hipStream_t s);
 int launch_export_requests(pmk_query *q, int64_t first, int64_t n, double *x_out, int32_t *region_out, hipStream_t s);
 int launch_export_results(pmk_query *q, double *u_out, double *v_out, hipStream_t s);
+int grow_item_buffers(pmk_query *q, int64_t total);
 int launch_explicit_items(pmk_query *q, int *d_bad, hipStream_t s);
 int launch_query_mean(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
                       const double *d_c, int64_t nq, const double *d_xq, double *d_yq, hipStream_t s);

@@ -99,10 +99,19 @@ class DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
+def use_torch_stream(ctx):
+    """run the library's kernels on torch's current stream: device work of the two then orders itself, and
+    sharded_predict needs no host synchronisation between the library and torch.distributed"""
+    import torch
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.shares_torch_stream = True
+
+
 def sharded_predict(query, theta, weight_theta, radius, delta, P_global, rank, world, group=None):
-    """One predict step of a sharded model (see bench.py).  `query` holds THIS rank's queries; the model behind it
-    holds the leaves leaf_range(rank, world, P_global).  plan (own queries) -> requests to the owners -> items ->
-    results back -> mixture.  Returns this rank's item count."""
+    """One predict step of a sharded model driven from the host language over torch.distributed (the same step as
+    pmk_query_predict_sharded, which keeps the exchange inside the library on its own RCCL communicator).  `query`
+    holds THIS rank's queries; the model behind it holds the leaves leaf_range(rank, world, P_global).  plan (own
+    queries) -> requests to the owners -> items -> results back -> mixture.  Returns this rank's item count."""
     import torch
     from .mixture import DeviceQuery
     total = query.plan(radius, delta)
@@ -111,20 +120,27 @@ def sharded_predict(query, theta, weight_theta, radius, delta, P_global, rank, w
         query.mix(weight_theta)
         return total
     model, ctx = query.model, query.model.ctx
+    shared = getattr(ctx, "shares_torch_stream", False)   # one stream for both: stream order replaces the host syncs
+
+    def handoff():
+        if not shared:
+            ctx.synchronize()
+            torch.cuda.synchronize()
+
     off = query.region_offsets(P_global)
     send_rows = [n for _, n in segments(off, world)]
     xs = torch.empty((total, model.D), dtype=torch.float64, device="cuda")
     rg = torch.empty(total, dtype=torch.int32, device="cuda")
     query.export_requests(0, total, xs.data_ptr(), rg.data_ptr())
-    ctx.synchronize()                                   # library stream -> torch / RCCL
+    handoff()                                           # library stream -> torch / RCCL
     rx, rr, recv_rows = route_requests(xs, rg, send_rows, world, group)
-    torch.cuda.synchronize()
+    handoff()
     remote = DeviceQuery.from_items(model, rx.shape[0], rx.data_ptr(), rr.data_ptr())
     remote.items(theta)
     ru = torch.empty(rx.shape[0], dtype=torch.float64, device="cuda")
     rv = torch.empty(rx.shape[0], dtype=torch.float64, device="cuda")
     remote.export_results(ru.data_ptr(), rv.data_ptr())
-    ctx.synchronize()
+    handoff()
     u_ptr, v_ptr = query.item_buffers()
     if total > 0:
         u_out = torch.as_tensor(DevArray(u_ptr, total), device="cuda")
@@ -133,6 +149,6 @@ def sharded_predict(query, theta, weight_theta, radius, delta, P_global, rank, w
         u_out = torch.empty(0, dtype=torch.float64, device="cuda")
         v_out = torch.empty(0, dtype=torch.float64, device="cuda")
     return_results(ru, rv, u_out, v_out, send_rows, recv_rows, group)
-    torch.cuda.synchronize()
+    handoff()
     query.mix(weight_theta)
     return total

@@ -186,6 +186,16 @@ class DeviceQuery:
         _lib.check(self.L.pmk_query_item_buffers(self.h, C.byref(u), C.byref(v)))
         return u.value, v.value
 
+    def predict_sharded(self, comm, theta, weight_theta, radius, delta):
+        """pmk_query_predict_sharded: one predict step of a model sharded over `comm` (collective; RCCL inside the
+        library, everything on the context's stream).  Returns this rank's item count."""
+        d, w = theta.desc(), weight_theta.desc()
+        t = C.c_int64()
+        _lib.check(self.L.pmk_query_predict_sharded(self.h, comm.h, C.byref(d), C.byref(w), float(radius), float(delta),
+                                                    C.byref(t)), "pmk_query_predict_sharded")
+        self.total = t.value
+        return t.value
+
     def mix(self, weight_theta, q0=0, q1=None):
         d = weight_theta.desc()
         _lib.check(self.L.pmk_query_mix(self.h, C.byref(d), int(q0), int(self.Nq if q1 is None else q1)), "pmk_query_mix")

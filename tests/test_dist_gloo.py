@@ -124,3 +124,55 @@ def test_sharded_predict_matches_single_process_oracle(world, tmp_path):
         got_Y[int(d["q0"]):int(d["q1"])] = d["Yq"]
         got_V[int(d["q0"]):int(d["q1"])] = d["Vq"]
     assert np.allclose(got_Y, oY, rtol=0, atol=1e-12) and np.allclose(got_V, oV, rtol=1e-10, atol=1e-15)
+
+
+# ------------------------------------------------------------------------------------ config D shape: world 8, levels 11
+def _worker_counts(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import patchmixturekriging_amd as pmk
+        # every rank: the same levels = 11 tree (1024 leaves, 128 per rank = one depth-3 subtree), its own queries
+        rng = np.random.Generator(np.random.PCG64(3))
+        N, levels, radius, delta = 1 << 14, 11, 0.1 * np.sqrt(200.0 / 1024), 1e-5
+        X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+        Xq = np.stack([rng.uniform(-5, 5, 4000), rng.uniform(-10, 10, 4000)], 1)
+        root, X_parts, _ = pmk.setuppartition(X, levels)
+        P = len(X_parts)
+        assert P == 1024
+        hps = pmk.fetchhyperplanes(root)
+        q0, q1 = pd.query_range(rank, world, len(Xq))
+        regs = []
+        for x in Xq[q0:q1]:
+            home = pmk.findpartition(x, root)
+            reg, _, _, _ = pmk.findneighbourpartitions(x, radius, root, levels, hps, home, delta=delta)
+            regs += list(reg) + [home]
+        regs = np.sort(np.array(regs))
+        roff = np.concatenate([[0], np.cumsum(np.bincount(regs, minlength=P))])
+        seg = pd.segments(roff, world)
+        assert seg == pmk.shard_segments(roff, world)                 # the C ABI's host arithmetic is the same
+        for o, (first, cnt) in enumerate(seg):
+            lo, hi = pd.leaf_range(o, world, P)
+            assert np.all((regs[first:first + cnt] >= lo) & (regs[first:first + cnt] < hi))
+        send = [n for _, n in seg]
+        recv = pd.exchange_counts(send, world)
+        # all-to-all of the region ids themselves: every rank must receive only its own leaves, in requester order
+        rr = torch.empty(sum(recv), dtype=torch.int64)
+        pd.all_to_all_rows(rr, torch.from_numpy(regs), recv, send)
+        lo, hi = pd.leaf_range(rank, world, P)
+        assert bool(((rr >= lo) & (rr < hi)).all())
+        np.savez(os.path.join(tmp, "c%d.npz" % rank), send=np.array(send), recv=np.array(recv))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_levels11_segments_and_counts(tmp_path):
+    """BASELINE config D's sharding (8 ranks x 128 leaves of a levels = 11 tree): segment arithmetic, the count exchange
+    and an all-to-all with those counts; the count tables must be transposes of each other."""
+    world = 8
+    mp.spawn(_worker_counts, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    send = np.stack([np.load(os.path.join(str(tmp_path), "c%d.npz" % r))["send"] for r in range(world)])
+    recv = np.stack([np.load(os.path.join(str(tmp_path), "c%d.npz" % r))["recv"] for r in range(world)])
+    assert np.array_equal(send.T, recv) and send.sum() > 4000
