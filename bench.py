@@ -5,14 +5,18 @@ Metric (BASELINE.json): patch-solves/s (+ predict-points/s), 256 patches x 2k po
 2-D Spline34 mixGP (config C).  One "step" = one pass of the hot path over one batch of synthetic
 input that is already resident in HBM:
     fit step     : kernel-matrix build + Cholesky + weight solves for every patch of this rank
-    predict step : partition search + work-item plan, per-(query, region) prediction, all-gather of
-                   the per-item (u, v) across ranks (RCCL), mixture -- for every query of the job
+    predict step : partition search + work-item plan, requests to the leaf owners, per-(query, region)
+                   prediction, (u, v) back (RCCL inside libpmk_hip.so), mixture -- for every query of the job
 `value` = patch-solves/s over all ranks (fit steps timed as the contract says: W warm-up steps, K
 timed steps between barrier + synchronize, max over ranks).  predict-points/s is timed the same way
-in a second loop and reported beside it.  N GPUs: weak scaling -- every rank owns 256 leaves of one
-shared BSP tree (no data-path collective in fit; one all-gather in predict).
+in a second loop and reported beside it.  N GPUs: weak scaling -- every rank owns `patches` leaves of one
+shared BSP tree and `nq` queries (no data-path collective in fit; one request/response exchange in predict).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--nq NQ] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C|D|E] [--eps E] [--nq NQ] [--no-cpu]
+
+Configs (BASELINE.json): C = headline, 256 x 2000 per GPU.  D = 1024 x 2000 over 8 GPUs: 128 leaves and 524 288 queries
+per GPU (run with --gpus 8; `--config D --patches 1024 --nq 4194304` is the whole workload on one GPU).
+E = 3-D, 128 x 8192, fp32, checked against the fp64 device model in the same run.
 """
 import argparse
 import json
@@ -25,8 +29,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix/vector peak (not in the local guide)
+FP64_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix/vector peak (not in the local guide; measured 76.5-77.8)
 FP32_PEAK_TFLOPS = 157.3    # fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_TBS = 8.0          # spec; 6.29 TB/s is what a float4 copy achieves (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_TBS = 6.29
 
 
 def oracle_f(X):
@@ -40,16 +46,37 @@ def chol_flops(n):
     return n ** 3 / 3.0 + 2.0 * n ** 2
 
 
-def panel_flops(ld, tile=128):
-    """flops executed by chol_panel_kernel over one patch: per step k the rows below the diagonal block
-    get a GEMM of depth 128 k and a triangular 128-wide solve"""
-    nt = ld // tile
+def executed_step_flops(n, tile=128):
+    """flops the step launches execute for one patch: full-rectangle GEMMs on the padded tiles, block substitutions,
+    the look-ahead of every diagonal tile"""
+    nt = (n + tile - 1) // tile
     f = 0.0
     for k in range(nt - 1):
-        rows = ld - (k + 1) * tile
+        rows = (nt - k - 1) * tile
         f += 2.0 * rows * tile * (tile * k) + rows * tile * tile
-        f += tile * tile * (tile * k)        # look-ahead workgroup: symmetric update of the next diagonal tile
+        f += tile * tile * (tile * (k + 1))
     return f
+
+
+def host_cores():
+    """threads the CPU leg may use: the affinity mask, capped by the cgroup CPU quota of the box (a GPU box may show every
+    core of the host in its mask while the container is entitled to a share of them)"""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(np.ceil(quota))))
+    return cores, aff, quota
 
 
 def main():
@@ -57,16 +84,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nq", type=int, default=1 << 20, help="query points per GPU")
-    ap.add_argument("--patches", type=int, default=256, help="patches per GPU")
-    ap.add_argument("--n", type=int, default=2000, help="points per patch")
+    ap.add_argument("--nq", type=int, default=None, help="query points per GPU (default: 2^20; config D: 524288)")
+    ap.add_argument("--patches", type=int, default=None, help="patches per GPU (default 256; D: 128; E: 128)")
+    ap.add_argument("--n", type=int, default=None, help="points per patch (default 2000; E: 8192)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--eps", type=float, default=0.0,
                     help="overlap of the training sets (organizetrainingsets); 0.044 gives the ragged 'realistic' "
                          "variant of config C (n ~ 1.8k-2.2k per patch, SURVEY 8(d))")
-    ap.add_argument("--config", default="C", choices=["C", "E"],
-                    help="C: headline 2-D fp64 256 x 2000 (default).  E: 3-D, 128 x 8192, fp32 (BASELINE config E; "
-                         "not the headline: no CPU leg, fp32 MFMA peak)")
+    ap.add_argument("--config", default="C", choices=["C", "D", "E"])
+    ap.add_argument("--exchange", default=os.environ.get("PMK_BENCH_EXCHANGE", "abi"), choices=["abi", "torch"],
+                    help="N > 1: 'abi' = pmk_query_predict_sharded (the library's own RCCL communicator); 'torch' = the "
+                         "same step driven from Python over torch.distributed (patchmixturekriging_amd/dist.py)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,19 +118,21 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+            args.exchange = "torch"             # two ranks on one device: RCCL refuses duplicate GPUs
 
     import patchmixturekriging_amd as pmk
-    from patchmixturekriging_amd import mixture as M
+    from patchmixturekriging_amd import dist as pdist
     pmk.set_device(local_rank)
     ctx = pmk.default_context()
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)          # launch on torch's stream: its events then see our kernels
+    pdist.use_torch_stream(ctx)                 # launch on torch's stream: its events and collectives order with our kernels
 
-    # ---------------------------------------------------------------- synthetic input (config C, weak-scaled)
-    cfgE = args.config == "E"
-    if cfgE:
-        args.patches, args.n, args.no_cpu = 128, 8192, True
-    P, n = args.patches, args.n
+    # ---------------------------------------------------------------- synthetic input, weak-scaled
+    cfg = args.config
+    defaults = {"C": (256, 2000, 1 << 20), "D": (128, 2000, 1 << 19), "E": (128, 8192, 1 << 20)}[cfg]
+    P = args.patches or defaults[0]
+    n = args.n or defaults[1]
+    nq = args.nq or defaults[2]
+    cfgE = cfg == "E"
     levels_local = int(round(np.log2(P))) + 1
     assert 2 ** (levels_local - 1) == P, "--patches must be a power of two"
     levels = levels_local + int(round(np.log2(world)))
@@ -131,9 +161,29 @@ def main():
     dtype = "f32" if cfgE else "f64"
     model = pmk.DeviceModel(X_parts[lo:hi], [y[i] for i in X_parts_inds[lo:hi]], dtype=dtype)
     model.set_bsp(root, lo)
-    Nq = args.nq * world
+    Nq = nq * world
     Xq = rng.uniform(0, 1, (Nq, 3)) if cfgE else np.stack([rng.uniform(-5, 5, Nq), rng.uniform(-10, 10, Nq)], 1)
-    query = pmk.DeviceQuery(model, Xq[rank * args.nq:(rank + 1) * args.nq])   # queries are sharded like the leaves
+    query = pmk.DeviceQuery(model, Xq[rank * nq:(rank + 1) * nq])   # queries are sharded like the leaves
+
+    comm, exchange = None, "none"
+    if world > 1:
+        exchange = args.exchange
+        if exchange == "abi":
+            try:
+                idt = torch.zeros(pmk.context.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(pmk.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                comm = pmk.Comm(ctx, rank, world, bytes(idt.cpu().numpy().tobytes()))
+            except Exception as e:                                  # say so loudly; the step itself is the same
+                print("bench.py: the library's RCCL communicator could not be created (%s); using torch.distributed" % e,
+                      file=sys.stderr)
+                exchange = "torch"
+            flag = torch.tensor([1 if exchange == "torch" else 0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)              # all ranks must take the same path
+            if int(flag.item()) and exchange == "abi":
+                comm.close()
+                comm, exchange = None, "torch"
 
     def sync():
         torch.cuda.synchronize()
@@ -156,8 +206,6 @@ def main():
         return dt
 
     # ---------------------------------------------------------------- fit
-    stage_ms = {"kernel_matrix": [], "cholesky": [], "solve": [], "panel": []}
-
     def fit_step():
         model.fit(th, sigma2)
 
@@ -165,6 +213,9 @@ def main():
     info = model.info()
     assert np.all(info == 0), "a patch was not positive definite"
     # per-stage device times (HIP events on the launch stream) of a few extra steps
+    nt_max = (max(sizes[lo:hi]) + 127) // 128
+    stage_ms = {"kernel_matrix": [], "cholesky": [], "solve": [], "panel": []}
+    step_us = []
     ctx.L.pmk_ctx_enable_timers(ctx.h, 2)
     for _ in range(3):
         fit_step()
@@ -174,14 +225,20 @@ def main():
                 stage_ms[k].append(ctx.timer_ms(k))
             except pmk.PmkError:
                 pass
+        try:
+            step_us.append([ctx.timer_ms("step:%d" % i) * 1e3 for i in range(nt_max - 1)])
+        except pmk.PmkError:
+            pass
     stage = {k: float(np.median(v)) for k, v in stage_ms.items() if v}
+    if "panel" in stage:
+        stage["chol_steps"] = stage.pop("panel")        # the nt - 1 chol_step_kernel launches of a fit
 
     # ---------------------------------------------------------------- predict
-    from patchmixturekriging_amd import dist as pdist
-
     def predict_step():
-        # plan of this rank's queries (K5 + sort) -> all-to-all of the (point, region) requests to the leaf owners ->
-        # items (K4) -> all-to-all of (u, v) back (RCCL/xGMI) -> mixture (K6)
+        # plan of this rank's queries (K5 + sort) -> requests to the leaf owners -> items (K4) -> (u, v) back (RCCL over
+        # xGMI) -> mixture (K6)
+        if comm is not None:
+            return query.predict_sharded(comm, th, wth, radius, delta)
         return pdist.sharded_predict(query, th, wth, radius, delta, P * world, rank, world)
 
     ctx.L.pmk_ctx_enable_timers(ctx.h, 0)
@@ -196,50 +253,109 @@ def main():
             pstage[k] = ctx.timer_ms(k)
         except pmk.PmkError:
             pass
+    ctx.L.pmk_ctx_enable_timers(ctx.h, 0)
     Yq, Vq = query.fetch()
     assert np.all(np.isfinite(Yq)) and np.all(Vq >= 1e-12)
+
+    # ---------------------------------------------------------------- config E: the fp32 result against the fp64 device model
+    parity32 = None
+    if cfgE and world == 1:
+        m64 = pmk.DeviceModel(X_parts[lo:hi], [y[i] for i in X_parts_inds[lo:hi]])
+        m64.fit(th, sigma2)
+        assert np.all(m64.info() == 0)
+        m64.set_bsp(root, lo)
+        ns = min(nq, 1 << 16)
+        q64 = pmk.DeviceQuery(m64, Xq[:ns]); q64.plan(radius, delta); q64.items(th); q64.mix(wth)
+        Y64, V64 = q64.fetch()
+        q32 = pmk.DeviceQuery(model, Xq[:ns]); q32.plan(radius, delta); q32.items(th); q32.mix(wth)
+        Y32, V32 = q32.fetch()
+        d64, d32 = q64.debug(), q32.debug()
+        ids = all(np.array_equal(d64[k], d32[k]) for k in ("home", "item_offsets", "item_region", "item_t"))
+        c64, c32 = m64.get(0, 0), model.get(0, 0)
+        parity32 = {"queries": ns, "ids_and_t_identical": bool(ids),
+                    "max_rel_dY": float(np.max(np.abs(Y32 - Y64) / np.maximum(1, np.abs(Y64)))),
+                    "max_abs_dV": float(np.max(np.abs(V32 - V64))), "V_range": [float(V64.min()), float(V64.max())],
+                    "rel_dc_patch0": float(np.linalg.norm(c32 - c64) / np.linalg.norm(c64)),
+                    "bounds": "dY <= 1e-4, dV <= 5e-5 + 2e-3 V (tests/test_gpu_parity.py, eps32-scaled)"}
+        assert ids and parity32["max_rel_dY"] <= 1e-4 and np.all(np.abs(V32 - V64) <= 5e-5 + 2e-3 * V64), parity32
+        del q64, m64
 
     if rank != 0:
         if world > 1:
             dist.barrier()
+            if comm is not None:
+                comm.close()
             dist.destroy_process_group()
         return
 
-    # ---------------------------------------------------------------- roofline of the dominant kernel
-    nmax = max(sizes)
-    ld = ((nmax + 127) // 128) * 128
-    nt = ld // 128
+    # ---------------------------------------------------------------- rooflines (algorithmic work / device time)
+    mine = sizes[lo:hi]
+    peak = FP32_PEAK_TFLOPS if cfgE else FP64_PEAK_TFLOPS
+    esz = 4 if cfgE else 8
+    D = X.shape[1]
+    alg = sum(chol_flops(s) for s in mine)
     roof = None
-    if "panel" in stage:
-        flops = sum(panel_flops(((s + 127) // 128) * 128) for s in sizes[lo:hi])
-        roof = {"bound": "mfma", "kernel": "chol_panel_kernel", "achieved": flops / (stage["panel"] * 1e-3) / 1e12,
-                "peak": FP32_PEAK_TFLOPS if cfgE else FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
-                "launches_per_step": nt - 1, "avg_launch_ms": stage["panel"] / (nt - 1),
-                "alg_flops_per_launch": flops / (nt - 1)}
-    elif "cholesky" in stage:
-        flops = sum(chol_flops(s) for s in sizes[lo:hi])
-        roof = {"bound": "mfma", "kernel": "chol_diag_kernel+chol_panel_kernel", "achieved": flops / (stage["cholesky"] * 1e-3) / 1e12,
-                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
-    if roof:
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 per the gfx950
-        # correction + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command; see the file's note)
+    if "chol_steps" in stage and nt_max > 1:
+        launches = nt_max - 1
+        t_steps = stage["chol_steps"] * 1e-3
+        roof = {"bound": "mfma", "kernel": "chol_step_kernel",
+                "achieved": alg / t_steps / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": alg / t_steps / 1e12 / peak,
+                "traffic": None,
+                "launches_per_step": launches, "avg_launch_ms": stage["chol_steps"] / launches,
+                "alg_flops_per_launch": alg / launches,
+                "note": "algorithmic flops = sum over patches of n^3/3 + 2 n^2 (real n), / the device time of the nt-1 step "
+                        "launches (HIP events on the launch stream)",
+                "executed_flops_frac": sum(executed_step_flops(s) for s in mine) / t_steps / 1e12 / peak,
+                "step_launch_us": [round(float(v), 1) for v in np.median(np.array(step_us), axis=0)] if step_us else None}
+        try:    # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            if cfg == "C" and (P, n) == (256, 2000) and args.eps == 0:
+                roof["traffic"] = pmc["chol_step_kernel"]["hbm_bytes_per_dispatch"]
+                roof["traffic_source"] = "profiles/r02_pmc_summary.json"
+        except Exception:
+            pass
+    ms = dt_fit / args.steps * 1e3
+    roof_fit = {"bound": "mfma", "achieved": alg / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": alg / (ms * 1e-3) / 1e12 / peak, "note": "algorithmic flops / ms_per_step (K1 + factor + solves)"}
+    roof_k1 = None
+    if "kernel_matrix" in stage:
+        k1_bytes = sum(esz * (s * (s + 1) / 2 + s * D) for s in mine)
+        roof_k1 = {"bound": "hbm", "kernel": "kmat_slab_kernel", "achieved": k1_bytes / (stage["kernel_matrix"] * 1e-3) / 1e9,
+                   "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": k1_bytes / (stage["kernel_matrix"] * 1e-3) / 1e12 / HBM_PEAK_TBS,
+                   "frac_of_achievable_6.29": k1_bytes / (stage["kernel_matrix"] * 1e-3) / 1e12 / HBM_ACHIEVABLE_TBS,
+                   "note": "algorithmic bytes = s (n(n+1)/2 + n D) per patch: the lower triangle is what is materialised"}
+    roof_pred = None
+    if "items" in pstage and world == 1:
+        dbg = query.debug()
+        regs = dbg["item_region"]
+        nn = np.array(sizes, dtype=np.float64)[regs]
+        pf = float(np.sum(nn * nn + 4 * nn))
+        roof_pred = {"bound": "mfma", "kernel": "predict_strip_kernel", "achieved": pf / (pstage["items"] * 1e-3) / 1e12,
+                     "peak": peak, "unit": "TFLOP/s", "frac": pf / (pstage["items"] * 1e-3) / 1e12 / peak,
+                     "note": "n^2 + 4 n flops per (query, region) pair / device time of the strip kernel"}
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if "panel" in roof["kernel"] and (P, n) == (256, 2000) and args.eps == 0:
-                roof["traffic"] = pmc["chol_panel_kernel"]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r01_pmc_traffic.json"
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            if cfg == "C" and (P, n, nq) == (256, 2000, 1 << 20) and args.eps == 0:
+                roof_pred["traffic"] = pmc["predict_strip_kernel"]["hbm_bytes_per_dispatch"]
         except Exception:
             pass
 
-    # ---------------------------------------------------------------- CPU baseline (oracle = port), rank 0
+    # ---------------------------------------------------------------- CPU baseline (oracle = port), rank 0, N = 1
     cpu = None
-    if not args.no_cpu and world == 1:          # the CPU leg runs on rank 0 of the single-GPU run only
+    if not args.no_cpu and world == 1 and not cfgE:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as O
-        cores = min(16, os.cpu_count() or 1)
+        cores, aff_cores, quota = host_cores()
+        cores = min(cores, int(os.environ.get("PMK_BENCH_CPU_THREADS", cores)))
         oth, owth = O.kernel(O.SPLINE34, a), O.kernel(O.SPLINE34, 1 / radius)
-        sample = list(range(lo, lo + cores))
+        nsamp = min(cores, P)
+        sample = list(range(lo, lo + nsamp))
+        # faithful flavour: what the Julia code does algorithmically, ONE thread -- scalar kernel
+        # loop, LU solve for the weights, a second factorisation (Cholesky) for the variance; one patch
+        t = time.perf_counter()
+        O.fit_patch(oth, X_parts[sample[0]], y[X_parts_inds[sample[0]]], sigma2)
+        t_one = time.perf_counter() - t
         t = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:         # ctypes releases the GIL: one patch per core
             fits = list(ex.map(lambda r: O.fit_patch(oth, X_parts[r], y[X_parts_inds[r]], sigma2), sample))
@@ -258,6 +374,11 @@ def main():
         t = time.perf_counter()
         oY, oV = O.query_mixture(ob, oth, owth, Xs, cs, Ls, Xq[qs], radius, delta, nthreads=cores)
         t_cpu_pred = time.perf_counter() - t
+        t = time.perf_counter()
+        nq1 = min(len(qs), 200)
+        if nq1:
+            O.query_mixture(ob, oth, owth, Xs, cs, Ls, Xq[qs[:nq1]], radius, delta, nthreads=1)
+        t_pred_one = time.perf_counter() - t
         err_y = float(np.max(np.abs(Yq[qs] - oY) / np.maximum(1, np.abs(oY)))) if len(qs) else 0.0
         err_v = float(np.max(np.abs(Vq[qs] - oV) / (1e-9 + 1e-5 * oV))) if len(qs) else 0.0
         # "strong" flavour: same kernel loop, factorisations by LAPACK (scipy = OpenBLAS, the
@@ -283,17 +404,25 @@ def main():
         except Exception:
             pass
         cpu = {"value": len(sample) / t_cpu_fit, "unit": "patch-solves/s", "cores": cores, "kind": "port",
+               "cpu_count": os.cpu_count(), "affinity_cores": aff_cores, "cgroup_cpu_quota": quota,
+               "faithful_1thread": {"patch_solves_per_s": 1.0 / t_one,
+                                    "predict_points_per_s": nq1 / t_pred_one if nq1 else None,
+                                    "what": "C oracle on ONE thread: scalar kernel loop, LU for c, Cholesky for L; per-query TRSV"},
                "strong_lapack_patch_solves_per_s": strong,
-               "sample": "%d of %d patches (n=%d) by the C oracle (kernel loop + LU + Cholesky), one patch per thread"
-                         % (len(sample), P, n),
+               "sample": "%d of %d patches (n=%d) by the C oracle (kernel loop + LU + Cholesky), one patch per thread on the "
+                         "%d cores this box is entitled to (affinity mask capped by the cgroup quota)" % (len(sample), P, n, cores),
                "predict_points_per_s": len(qs) / t_cpu_pred if len(qs) else None,
                "predict_sample": "%d queries inside the sampled leaves, oracle querymixtureGP! on %d threads" % (len(qs), cores),
                "parity_vs_gpu": {"max_rel_dY": err_y, "max_dV_over_tol": err_v}}
 
-    ms = dt_fit / args.steps * 1e3
+    metric = {"C": "patch-solves/sec + predict-points/sec, 256 patches x 2k pts",
+              "D": "patch-solves/sec + predict-points/sec, 1024 patches x 2k pts over 8 GPUs (config D: 128 leaves per GPU)",
+              "E": "patch-solves/sec + predict-points/sec, 128 patches x 8k pts (config E)"}[cfg]
+    work = {"C": "mixGP 2-D Spline34(1/15), %d BSP patches x %d points per GPU, sigma2=1e-5 (BASELINE config C)",
+            "D": "mixGP 2-D Spline34(1/15), %d BSP patches x %d points per GPU, sigma2=1e-5 (BASELINE config D shape)",
+            "E": "3-D Spline34(8), %d BSP patches x %d points per GPU, sigma2=1e-3, fp32 (BASELINE config E)"}[cfg] % (P, n)
     out = {
-        "metric": "patch-solves/sec + predict-points/sec, 256 patches x 2k pts" if not cfgE else
-                  "patch-solves/sec + predict-points/sec, 128 patches x 8k pts (config E)",
+        "metric": metric,
         "value": P * world * args.steps / dt_fit,
         "unit": "patch-solves/s",
         "predict_points_per_s": Nq * args.steps / dt_pred,
@@ -301,21 +430,27 @@ def main():
         "ms_per_step": ms, "predict_ms_per_step": dt_pred / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dtype, "data": "synthetic",
-        "config": {"workload": ("3-D Spline34(8), %d BSP patches x %d points per GPU, sigma2=1e-3, fp32 (BASELINE config E)"
-                                if cfgE else
-                                "mixGP 2-D Spline34(1/15), %d BSP patches x %d points per GPU, sigma2=1e-5 (BASELINE config C)")
-                               % (P, n),
+        "config": {"workload": work,
                    "patches_per_gpu": P, "points_per_patch": n, "patch_sizes_minmax": [min(sizes), max(sizes)],
-                   "queries_per_gpu": args.nq, "radius": radius, "items_per_query": total_items / args.nq,
-                   "levels": levels, "parallelism": "leaves and queries sharded (%d leaves per GPU); all-to-all of requests and of (u,v)" % P,
-                   "bsp_build_s": t_bsp},
+                   "eps": args.eps, "queries_per_gpu": nq, "radius": radius, "items_per_query": total_items / nq,
+                   "levels": levels,
+                   "parallelism": "leaves and queries sharded (%d leaves per GPU); requests to the leaf owners and (u,v) back by "
+                                  "grouped RCCL send/recv" % P,
+                   "exchange": exchange, "bsp_build_s": t_bsp},
         "stage_ms": {**stage, **{"predict_" + k: v for k, v in pstage.items()}},
         "roofline": roof,
+        "roofline_fit_step": roof_fit,
+        "roofline_kernel_matrix": roof_k1,
+        "roofline_predict": roof_pred,
         "cpu_baseline": cpu,
     }
+    if parity32 is not None:
+        out["parity_vs_fp64"] = parity32
     print(json.dumps(out))
     if world > 1:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

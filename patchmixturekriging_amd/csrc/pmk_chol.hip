@@ -208,22 +208,18 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
                                                            real *__restrict__ z, int32_t *__restrict__ info)
 {
     __shared__ real lds[TRI_LDS_DOUBLES];
-    // logical (patch slot, block row) from the XCD-aware id: the workgroups of a patch land on one XCD and share the
-    // I-operand (block row k of L) through that XCD's L2; within an XCD the critical workgroups (bx == 0) come first
-    const int nwg = nactive * G;
-    const int lid = xcd_remap(blockIdx.x, nwg);
-    int slot, bx;
-    if (G == 1) {
-        slot = lid; bx = 0;
-    } else if ((nactive & 7) == 0) {
-        const int per = nactive >> 3, chunk = per * G;
-        const int xcd = lid / chunk, loc = lid - xcd * chunk;
-        if (loc < per) { slot = xcd * per + loc; bx = 0; }
-        else { const int j = loc - per; slot = xcd * per + j / (G - 1); bx = 1 + j % (G - 1); }
-    } else {
-        if (lid < nactive) { slot = lid; bx = 0; }
-        else { const int j = lid - nactive; slot = j / (G - 1); bx = 1 + j % (G - 1); }
-    }
+    // (patch slot, block row) from the hardware block id.  Blocks are dealt round-robin over the 8 XCDs (block b runs on
+    // XCD b % 8): XCD x takes the patch slots x, x + 8, x + 16, ... (sizes interleaved, so ragged batches load the XCDs
+    // evenly) and ALL block rows of those patches -- they stream the same block row k of L, which that XCD's L2 then
+    // fetches once.  Within an XCD the critical workgroups (bx == 0) have the lowest ids: they are dispatched first.
+    // The grid is padded to 8 x ceil(nactive / 8) x G; the surplus workgroups of the short XCDs exit here.
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int per = (nactive - xcd + 7) >> 3;             // patch slots of this XCD
+    if (idx >= per * G) return;
+    int loc, bx;
+    if (idx < per) { loc = idx; bx = 0; }
+    else { const int j = idx - per; loc = j / (G - 1); bx = 1 + j % (G - 1); }
+    const int slot = xcd + 8 * loc;
     const int pid = order[slot];
     const PatchDesc pd = descs[pid];
     const int k = launch - (max_nt - pd.nt);      // this patch's block column (end-aligned schedule): 0 <= k < nt - 1
@@ -490,7 +486,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
             }
             PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].first, s));
         }
-        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(nactive * G)), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
+        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(8 * ((nactive + 7) / 8) * G)), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
                            m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info);
         if (fine) {
             PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].second, s));
