@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PMK_VERSION 100
+#define PMK_VERSION 101
 
 /* kernel families = the isbits kernel structs of src/misc/declarations.jl:18-45,65-67,75-111 */
 enum {
@@ -83,16 +83,22 @@ int  pmk_ctx_timer_ms(pmk_ctx *ctx, const char *stage, double *ms);
 /* ---- BSP: host, exact (integer outputs are part of the parity contract) --------------- */
 /* setuppartition(X, levels)  src/patchwork/partition.jl:106-129 (+ gethyperplane :86-100,
  * splitpoints :64-83, createchildren :166-217, labelleafnodes :131-159).
- * sign_mode +1: v = +z/|z| ; -1: v = -sign(z1) z/|z|  (SVD sign convention) */
-int     pmk_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, pmk_bsp **out);
+ * Two Julia-stdlib behaviours that the reference's text does not fix are switches, stored with the tree and honoured by
+ * every later search on it (host and device):
+ *   sign_mode +1: v = +z/|z| ; -1: v = -sign(z1) z/|z|           (sign convention of svd)
+ *   dot_mode   0: dot(v, x) = separate multiplies and adds ; 1: a chain of fused multiply-adds
+ *                 (LinearAlgebra.dot -> BLAS ddot: whether its short loop was contracted depends on the BLAS build) */
+int     pmk_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, int dot_mode, pmk_bsp **out);
 /* the same build on the GPU (X: host or device pointer, point-major N x D; N < 2^31): level-by-level segmented
  * pairwise sums, radix-sort medians and stable splits; every output equals pmk_bsp_build's bit for bit.  Blocks. */
-int     pmk_bsp_build_device(pmk_ctx *ctx, int D, int64_t N, const double *X, int levels, int sign_mode, pmk_bsp **out);
+int     pmk_bsp_build_device(pmk_ctx *ctx, int D, int64_t N, const double *X, int levels, int sign_mode, int dot_mode,
+                             pmk_bsp **out);
 /* rebuild a tree from its pre-order hyperplanes (for shipping a tree between processes) */
-int     pmk_bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, pmk_bsp **out);
+int     pmk_bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, int dot_mode, pmk_bsp **out);
 void    pmk_bsp_destroy(pmk_bsp *bsp);
 int     pmk_bsp_dim(const pmk_bsp *bsp);
 int     pmk_bsp_levels(const pmk_bsp *bsp);
+int     pmk_bsp_dot_mode(const pmk_bsp *bsp);
 int64_t pmk_bsp_num_leaves(const pmk_bsp *bsp);
 int64_t pmk_bsp_num_points(const pmk_bsp *bsp);
 /* fetchhyperplanes(root)  src/RKHS/mixtureGP.jl:322-334 : pre-order; hp_v is D x (P-1).

@@ -60,7 +60,7 @@ def lib():
     L.pmko_kernel_matrix.argtypes = [_kp, C.c_int, C.c_int64, _dp, _dp, C.c_int64]
     L.pmko_cross_kernel_matrix.argtypes = [_kp, C.c_int, C.c_int64, _dp, C.c_int64, _dp, _dp, C.c_int64]
     L.pmko_bsp_build.restype = C.c_void_p
-    L.pmko_bsp_build.argtypes = [C.c_int, C.c_int64, _dp, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.pmko_bsp_build.argtypes = [C.c_int, C.c_int64, _dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.pmko_bsp_free.argtypes = [C.c_void_p]
     L.pmko_bsp_num_leaves.restype = C.c_int64
     L.pmko_bsp_num_leaves.argtypes = [C.c_void_p]
@@ -140,13 +140,13 @@ def cross_kernel_matrix(th, X, Z):
 class BSP:
     """setuppartition (partition.jl:106-129) result; indices are 0-based."""
 
-    def __init__(self, X, levels, sign_mode=1):
+    def __init__(self, X, levels, sign_mode=1, dot_mode=0):
         X = _pts(X)
         self.X = X
         self.N, self.D = X.shape
         self.levels = levels
         st = C.c_int(0)
-        self.h = lib().pmko_bsp_build(self.D, self.N, _d(X), levels, sign_mode, C.byref(st))
+        self.h = lib().pmko_bsp_build(self.D, self.N, _d(X), levels, sign_mode, int(dot_mode), C.byref(st))
         if not self.h:
             raise RuntimeError("pmko_bsp_build failed: %d" % st.value)
         self.P = lib().pmko_bsp_num_leaves(self.h)

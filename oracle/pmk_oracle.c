@@ -238,6 +238,7 @@ double pmko_median(int64_t n, double *v)
  * ---------------------------------------------------------------------------------------- */
 struct pmko_bsp {
     int D, levels;
+    int dot_mode;       /* see dot_seq */
     int64_t P;          /* leaves = 2^(levels-1) */
     int64_t N;
     double *v;          /* (P-1) x D, heap order */
@@ -247,17 +248,21 @@ struct pmko_bsp {
     int64_t *pre;       /* pre-order rank -> heap index (P-1) */
 };
 
-static double dot_seq(int D, const double *a, const double *b)
+static double dot_seq(int D, const double *a, const double *b, int mode)
 {
-    /* [stdlib] dot on a short Vector{Float64}: sequential multiply-add, no FMA */
+    /* [stdlib] dot on a short Vector{Float64} reaches BLAS ddot: a sequential loop whose multiply-add is either left
+     * as two operations (mode 0, default) or contracted into fused multiply-adds (mode 1) by the BLAS build.  Which one
+     * a Julia install runs is not decidable from the reference's text: both are restated, the product has the same
+     * switch, and the tests hold the two implementations to each other in both modes. */
     double s = a[0] * b[0];
-    for (int d = 1; d < D; ++d) s = s + a[d] * b[d];
+    if (mode) { for (int d = 1; d < D; ++d) s = fma(a[d], b[d], s); }
+    else { for (int d = 1; d < D; ++d) s = s + a[d] * b[d]; }
     return s;
 }
 
 /* gethyperplane partition.jl:86-100 + splitpoints :64-83.  idx: the node's points in original
  * order.  Writes v, c, and the left mask. */
-static int gethyperplane(int D, const double *X, const int64_t *idx, int64_t n, int sign_mode,
+static int gethyperplane(int D, const double *X, const int64_t *idx, int64_t n, int sign_mode, int dot_mode,
                          double *v, double *c, uint8_t *left)
 {
     double mu[16], z[16];
@@ -276,7 +281,7 @@ static int gethyperplane(int D, const double *X, const int64_t *idx, int64_t n, 
     }
     double *ev = (double *)malloc(sizeof(double) * (size_t)n * 2);
     if (!ev) return -2;
-    for (int64_t i = 0; i < n; ++i) ev[i] = dot_seq(D, v, X + idx[i] * D);   /* :69 */
+    for (int64_t i = 0; i < n; ++i) ev[i] = dot_seq(D, v, X + idx[i] * D, dot_mode);   /* :69 */
     memcpy(ev + n, ev, sizeof(double) * (size_t)n);
     *c = pmko_median(n, ev + n);                                     /* :70 */
     for (int64_t i = 0; i < n; ++i) left[i] = ev[i] < *c;             /* :72-80 strict */
@@ -296,7 +301,7 @@ static int build_rec(pmko_bsp *t, const double *X, int sign_mode, int64_t node, 
     }
     uint8_t *left = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
     if (!left) return -2;
-    int st = gethyperplane(t->D, X, idx, n, sign_mode, t->v + node * t->D, t->c + node, left);
+    int st = gethyperplane(t->D, X, idx, n, sign_mode, t->dot_mode, t->v + node * t->D, t->c + node, left);
     if (st) { free(left); free(idx); return st; }
     int64_t nl = 0;
     for (int64_t i = 0; i < n; ++i) nl += left[i];
@@ -322,12 +327,12 @@ static void preorder(const pmko_bsp *t, int64_t node, int depth, int64_t *k)
 }
 
 /* setuppartition partition.jl:106-129 + labelleafnodes :131-159 */
-pmko_bsp *pmko_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, int *status)
+pmko_bsp *pmko_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, int dot_mode, int *status)
 {
     int st = 0;
     if (D < 1 || D > 16 || levels < 2 || levels > 40 || N < 1) { if (status) *status = -1; return NULL; }
     pmko_bsp *t = (pmko_bsp *)calloc(1, sizeof(*t));
-    t->D = D; t->levels = levels; t->N = N;
+    t->D = D; t->levels = levels; t->N = N; t->dot_mode = dot_mode != 0;
     t->P = (int64_t)1 << (levels - 1);
     t->v = (double *)calloc((size_t)((t->P - 1) * D), sizeof(double));
     t->c = (double *)calloc((size_t)(t->P - 1), sizeof(double));
@@ -385,7 +390,7 @@ int64_t pmko_bsp_findpartition(const pmko_bsp *t, const double *x)
 {
     int64_t node = 0;
     for (int l = 1; l <= t->levels - 1; ++l) {
-        if (dot_seq(t->D, t->v + node * t->D, x) < t->c[node]) node = 2 * node + 1;
+        if (dot_seq(t->D, t->v + node * t->D, x, t->dot_mode) < t->c[node]) node = 2 * node + 1;
         else node = 2 * node + 2;
     }
     return node - (t->P - 1);
@@ -396,7 +401,7 @@ static void find_eps(const pmko_bsp *t, const double *x, int64_t node, int depth
                      int64_t *list, int64_t *cnt)
 {
     if (depth == t->levels - 1) { list[(*cnt)++] = node - (t->P - 1); return; }
-    double e = dot_seq(t->D, t->v + node * t->D, x);
+    double e = dot_seq(t->D, t->v + node * t->D, x, t->dot_mode);
     if (e < t->c[node] + eps) find_eps(t, x, 2 * node + 1, depth + 1, eps, list, cnt);
     if (e > t->c[node] - eps) find_eps(t, x, 2 * node + 2, depth + 1, eps, list, cnt);
 }
@@ -443,7 +448,7 @@ int64_t pmko_bsp_neighbours(const pmko_bsp *t, const double *p, double radius, d
     for (int64_t i = 0; i < t->P - 1; ++i) {
         const double *u = t->v + t->pre[i] * D;
         double c = t->c[t->pre[i]];
-        double tt = -dot_seq(D, u, p) + c;                            /* :361 */
+        double tt = -dot_seq(D, u, p, t->dot_mode) + c;                /* :361 */
         for (int d = 0; d < D; ++d) z[d] = p[d] + tt * u[d];          /* :362 */
         if (ts) ts[i] = tt;
         if (zs) for (int d = 0; d < D; ++d) zs[d + i * D] = z[d];

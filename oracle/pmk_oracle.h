@@ -64,7 +64,8 @@ void   pmko_cross_kernel_matrix(const pmko_kernel *th, int D, int64_t n, const d
 typedef struct pmko_bsp pmko_bsp;
 /* sign_mode: +1 -> v = +z/|z| (LAPACK gesdd on the D x 1 parent, Julia's svd(adjoint));
  *            -1 -> v = -sign(z1) z/|z| (dense 1 x D path).  See SURVEY Appendix A.1. */
-pmko_bsp *pmko_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, int *status);
+/* dot_mode: 0 -> dot(v, x) as separate multiplies and adds; 1 -> as a chain of fused multiply-adds (see dot_seq) */
+pmko_bsp *pmko_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, int dot_mode, int *status);
 void      pmko_bsp_free(pmko_bsp *t);
 int       pmko_bsp_levels(const pmko_bsp *t);
 int       pmko_bsp_dim(const pmko_bsp *t);

@@ -55,12 +55,13 @@ SIGNATURES = {
     "pmk_ctx_destroy": (None, [_vp]),
     "pmk_ctx_enable_timers": (C.c_int, [_vp, C.c_int]),
     "pmk_ctx_timer_ms": (C.c_int, [_vp, C.c_char_p, _dp]),
-    "pmk_bsp_build": (C.c_int, [C.c_int, C.c_int64, _dp, C.c_int, C.c_int, _vpp]),
-    "pmk_bsp_build_device": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, _vpp]),
-    "pmk_bsp_from_hyperplanes": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _vpp]),
+    "pmk_bsp_build": (C.c_int, [C.c_int, C.c_int64, _dp, C.c_int, C.c_int, C.c_int, _vpp]),
+    "pmk_bsp_build_device": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, _vpp]),
+    "pmk_bsp_from_hyperplanes": (C.c_int, [C.c_int, C.c_int, _dp, _dp, C.c_int, _vpp]),
     "pmk_bsp_destroy": (None, [_vp]),
     "pmk_bsp_dim": (C.c_int, [_vp]),
     "pmk_bsp_levels": (C.c_int, [_vp]),
+    "pmk_bsp_dot_mode": (C.c_int, [_vp]),
     "pmk_bsp_num_leaves": (C.c_int64, [_vp]),
     "pmk_bsp_num_points": (C.c_int64, [_vp]),
     "pmk_bsp_arrays": (C.c_int, [_vp, _dp, _dp, _ip, _ip]),

@@ -20,9 +20,9 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t);
-int bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, BspArrays &t);
-int bsp_build_device(pmk_ctx *c, int D, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t);
+int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, int dot_mode, BspArrays &t);
+int bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, int dot_mode, BspArrays &t);
+int bsp_build_device(pmk_ctx *c, int D, int64_t N, const double *X, int levels, int sign_mode, int dot_mode, BspArrays &t);
 int bsp_assign_device(pmk_ctx *c, const BspArrays &t, int64_t N, const double *X, double eps, int64_t *offsets,
                       int64_t *inds, int64_t *list_offsets, int64_t *lists);
 int64_t bsp_find(const BspArrays &t, const double *x);
@@ -239,7 +239,7 @@ int pmk_ctx_timer_ms(pmk_ctx *ctx, const char *stage, double *ms)
 }
 
 // ------------------------------------------------------------------------------------------ BSP
-int pmk_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, pmk_bsp **out)
+int pmk_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, int dot_mode, pmk_bsp **out)
 {
     if (!out) { set_error("pmk_bsp_build: out is NULL"); return -6; }
     *out = nullptr;
@@ -249,13 +249,14 @@ int pmk_bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, 
     if ((N >> (levels - 1)) < 1) { set_error("pmk_bsp_build: N=%lld < 2^(levels-1)", (long long)N); return -4; }
     pmk_bsp *b = new (std::nothrow) pmk_bsp();
     if (!b) { set_error("out of memory"); return -100; }
-    int rc = bsp_build(D, N, X, levels, sign_mode, b->t);
+    int rc = bsp_build(D, N, X, levels, sign_mode, dot_mode != 0, b->t);
     if (rc) { delete b; return rc; }
     *out = b;
     return 0;
 }
 
-int pmk_bsp_build_device(pmk_ctx *ctx, int D, int64_t N, const double *X, int levels, int sign_mode, pmk_bsp **out)
+int pmk_bsp_build_device(pmk_ctx *ctx, int D, int64_t N, const double *X, int levels, int sign_mode, int dot_mode,
+                         pmk_bsp **out)
 {
     if (!out) { set_error("pmk_bsp_build_device: out is NULL"); return -6; }
     *out = nullptr;
@@ -267,20 +268,20 @@ int pmk_bsp_build_device(pmk_ctx *ctx, int D, int64_t N, const double *X, int le
     PMK_HIP(hipSetDevice(ctx->device));
     pmk_bsp *b = new (std::nothrow) pmk_bsp();
     if (!b) { set_error("out of memory"); return -100; }
-    int rc = bsp_build_device(ctx, D, N, X, levels, sign_mode, b->t);
+    int rc = bsp_build_device(ctx, D, N, X, levels, sign_mode, dot_mode != 0, b->t);
     if (rc) { delete b; return rc; }
     *out = b;
     return 0;
 }
 
-int pmk_bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, pmk_bsp **out)
+int pmk_bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, int dot_mode, pmk_bsp **out)
 {
     if (!out || !hp_v || !hp_c) { set_error("pmk_bsp_from_hyperplanes: NULL argument"); return -1; }
     *out = nullptr;
     if (D < 1 || D > MAX_D || levels < 2 || levels > 31) { set_error("pmk_bsp_from_hyperplanes: bad D/levels"); return -1; }
     pmk_bsp *b = new (std::nothrow) pmk_bsp();
     if (!b) { set_error("out of memory"); return -100; }
-    bsp_from_hyperplanes(D, levels, hp_v, hp_c, b->t);
+    bsp_from_hyperplanes(D, levels, hp_v, hp_c, dot_mode != 0, b->t);
     *out = b;
     return 0;
 }
@@ -288,6 +289,7 @@ int pmk_bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double
 void pmk_bsp_destroy(pmk_bsp *bsp) { delete bsp; }
 int pmk_bsp_dim(const pmk_bsp *bsp) { return bsp ? bsp->t.D : -1; }
 int pmk_bsp_levels(const pmk_bsp *bsp) { return bsp ? bsp->t.levels : -1; }
+int pmk_bsp_dot_mode(const pmk_bsp *bsp) { return bsp ? bsp->t.dot_mode : -1; }
 int64_t pmk_bsp_num_leaves(const pmk_bsp *bsp) { return bsp ? bsp->t.P : -1; }
 int64_t pmk_bsp_num_points(const pmk_bsp *bsp) { return bsp ? bsp->t.N : -1; }
 
@@ -722,6 +724,7 @@ int pmk_model_set_bsp(pmk_model *m, const pmk_bsp *bsp, int64_t leaf_base)
         PMK_HIP(hipMemcpy(m->d_pre, pre32.data(), sizeof(int32_t) * pre32.size(), hipMemcpyHostToDevice));
     }
     m->levels = t.levels;
+    m->dot_mode = t.dot_mode;
     m->P_global = t.P;
     m->leaf_base = leaf_base;
     return 0;

@@ -14,10 +14,15 @@
 
 namespace pmk {
 
-static inline double dot_seq(int D, const double *a, const double *b)
+// [Julia stdlib] dot(::Vector{Float64}, ::Vector{Float64}) reaches BLAS ddot; for the 1..4-element vectors of this
+// path that is a short sequential loop whose multiply-add may or may not have been contracted by the BLAS build:
+// mode 0 = separate multiply and add (the default), mode 1 = a chain of fused multiply-adds.  Both are exact
+// restatements of *a* ddot; which one a given Julia install runs cannot be decided without running it.
+static inline double dot_seq(int D, const double *a, const double *b, int mode)
 {
     double s = a[0] * b[0];
-    for (int d = 1; d < D; ++d) s = s + a[d] * b[d];
+    if (mode) { for (int d = 1; d < D; ++d) s = std::fma(a[d], b[d], s); }
+    else { for (int d = 1; d < D; ++d) s = s + a[d] * b[d]; }
     return s;
 }
 
@@ -127,9 +132,9 @@ void bsp_fill_preorder(BspArrays &t)
 }
 
 // setuppartition (partition.jl:106-129)
-int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t)
+int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, int dot_mode, BspArrays &t)
 {
-    t.D = D; t.levels = levels; t.N = N;
+    t.D = D; t.levels = levels; t.N = N; t.dot_mode = dot_mode;
     t.P = (int64_t)1 << (levels - 1);
     t.v.assign((size_t)((t.P - 1) * D), 0.0);
     t.c.assign((size_t)(t.P - 1), 0.0);
@@ -154,7 +159,7 @@ int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, BspA
             double *v = t.v.data() + (heap0 + nd) * D;
             bsp_direction(D, mu, n, X + idx[0] * D, sign_mode, v);      // :89-94 (x1 = first point of the node)
             ev.resize((size_t)n);
-            for (int64_t i = 0; i < n; ++i) ev[(size_t)i] = dot_seq(D, v, X + idx[i] * D);   // splitpoints :69
+            for (int64_t i = 0; i < n; ++i) ev[(size_t)i] = dot_seq(D, v, X + idx[i] * D, dot_mode);   // splitpoints :69
             evs = ev;
             const double c = median_inplace(evs);                        // :70
             t.c[(size_t)(heap0 + nd)] = c;
@@ -177,9 +182,9 @@ int bsp_build(int D, int64_t N, const double *X, int levels, int sign_mode, BspA
     return 0;
 }
 
-int bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, BspArrays &t)
+int bsp_from_hyperplanes(int D, int levels, const double *hp_v, const double *hp_c, int dot_mode, BspArrays &t)
 {
-    t.D = D; t.levels = levels; t.N = 0;
+    t.D = D; t.levels = levels; t.N = 0; t.dot_mode = dot_mode;
     t.P = (int64_t)1 << (levels - 1);
     t.v.assign((size_t)((t.P - 1) * D), 0.0);
     t.c.assign((size_t)(t.P - 1), 0.0);
@@ -199,7 +204,7 @@ int64_t bsp_find(const BspArrays &t, const double *x)
 {
     int64_t node = 0;
     for (int l = 1; l < t.levels; ++l)
-        node = (dot_seq(t.D, t.v.data() + node * t.D, x) < t.c[(size_t)node]) ? 2 * node + 1 : 2 * node + 2;
+        node = (dot_seq(t.D, t.v.data() + node * t.D, x, t.dot_mode) < t.c[(size_t)node]) ? 2 * node + 1 : 2 * node + 2;
     return node - (t.P - 1);
 }
 
@@ -214,7 +219,7 @@ static int64_t find_eps(const BspArrays &t, const double *x, double eps, int64_t
         const int64_t node = stack.back();
         stack.pop_back();
         if (node >= first_leaf) { out[cnt++] = node - first_leaf; continue; }
-        const double e = dot_seq(t.D, t.v.data() + node * t.D, x);
+        const double e = dot_seq(t.D, t.v.data() + node * t.D, x, t.dot_mode);
         const double c = t.c[(size_t)node];
         if (e > c - eps) stack.push_back(2 * node + 2);     // popped second
         if (e < c + eps) stack.push_back(2 * node + 1);     // popped first
@@ -260,7 +265,7 @@ int64_t bsp_neighbours(const BspArrays &t, const double *p, double radius, doubl
     for (int64_t i = 0; i < t.P - 1; ++i) {
         const int64_t h = t.pre[(size_t)i];
         const double *u = t.v.data() + h * D;
-        const double tt = -dot_seq(D, u, p) + t.c[(size_t)h];
+        const double tt = -dot_seq(D, u, p, t.dot_mode) + t.c[(size_t)h];
         double s = 0.0;
         for (int d = 0; d < D; ++d) {
             const double zd = p[d] + tt * u[d];

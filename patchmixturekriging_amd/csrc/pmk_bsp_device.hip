@@ -18,7 +18,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "pmk_internal.h"
+#include "pmk_device.h"
 
 namespace pmk {
 
@@ -62,16 +62,16 @@ __global__ void first_points_kernel(const double *__restrict__ Xp, const int64_t
 
 template <int D>
 __global__ void project_kernel(int64_t N, const double *__restrict__ Xp, const int32_t *__restrict__ node_of,
-                               const double *__restrict__ v, double *__restrict__ e)
+                               const double *__restrict__ v, double *__restrict__ e, int dot_mode)
 {
 #pragma clang fp contract(off)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const double *u = v + (int64_t)node_of[i] * D;
-    double s = u[0] * Xp[i * D];
+    double x[D];
 #pragma unroll
-    for (int d = 1; d < D; ++d) s = s + u[d] * Xp[i * D + d];
-    e[i] = s;
+    for (int d = 0; d < D; ++d) x[d] = Xp[i * D + d];
+    e[i] = dot_seq<D>(u, x, dot_mode);
 }
 
 // c per node from the in-segment sorted projections (Statistics.median: a/2 + b/2 for even counts)
@@ -152,7 +152,7 @@ struct DevBuf {
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 template <int D>
-int build_levels(pmk_ctx *c, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t)
+int build_levels(pmk_ctx *c, int64_t N, const double *X, int levels, int sign_mode, int dot_mode, BspArrays &t)
 {
     hipStream_t s = c->stream;
     const int64_t P = t.P;
@@ -223,7 +223,7 @@ int build_levels(pmk_ctx *c, int64_t N, const double *X, int levels, int sign_mo
         }
         PMK_HIP(hipMemcpyAsync(d_v, vlevel.data(), sizeof(double) * vlevel.size(), hipMemcpyHostToDevice, s));
         // ---- 2. projections
-        hipLaunchKernelGGL((project_kernel<D>), dim3(blocks_for(N, 256)), dim3(256), 0, s, N, Xp, node, d_v, e);
+        hipLaunchKernelGGL((project_kernel<D>), dim3(blocks_for(N, 256)), dim3(256), 0, s, N, Xp, node, d_v, e, dot_mode);
         // ---- 3. medians: sort by e, then stably by node id
         const double *sorted = e1;
         PMK_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, e, e1, node, node_s, (int)N, 0, 64, s));
@@ -264,7 +264,7 @@ template <int D, bool FILL>
 __global__ void eps_walk_kernel(int64_t N, const double *__restrict__ X, const double *__restrict__ v,
                                 const double *__restrict__ c, int64_t P, double eps, int32_t *__restrict__ cnt,
                                 unsigned long long *__restrict__ leaf_cnt, const int64_t *__restrict__ loff,
-                                int32_t *__restrict__ lists, int32_t *__restrict__ pair_point)
+                                int32_t *__restrict__ lists, int32_t *__restrict__ pair_point, int dot_mode)
 {
 #pragma clang fp contract(off)
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -292,9 +292,7 @@ __global__ void eps_walk_kernel(int64_t N, const double *__restrict__ X, const d
             continue;
         }
         const double *u = v + node * D;
-        double e = u[0] * x[0];
-#pragma unroll
-        for (int d = 1; d < D; ++d) e = e + u[d] * x[d];
+        const double e = dot_seq<D>(u, x, dot_mode);
         const double cc = c[node];
         if (e > cc - eps) stack[sp++] = 2 * node + 2;     // popped second
         if (e < cc + eps) stack[sp++] = 2 * node + 1;     // popped first
@@ -321,7 +319,7 @@ int assign_levels(pmk_ctx *c, const BspArrays &t, int64_t N, const double *X, do
     PMK_HIP(hipMemsetAsync(leaf_cnt, 0, sizeof(unsigned long long) * (size_t)P, s));
     PMK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(N + 1), s));
     hipLaunchKernelGGL((eps_walk_kernel<D, false>), dim3(blocks_for(N, 256)), dim3(256), 0, s, N, dX, d_v, d_c, P, eps, cnt,
-                       leaf_cnt, nullptr, nullptr, nullptr);
+                       leaf_cnt, nullptr, nullptr, nullptr, t.dot_mode);
     std::vector<unsigned long long> hcnt((size_t)P);
     PMK_HIP(hipMemcpyAsync(hcnt.data(), leaf_cnt, sizeof(unsigned long long) * (size_t)P, hipMemcpyDeviceToHost, s));
     PMK_HIP(hipStreamSynchronize(s));
@@ -344,7 +342,7 @@ int assign_levels(pmk_ctx *c, const BspArrays &t, int64_t N, const double *X, do
     size_t tb = tmp_bytes;
     PMK_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, cnt, loff, (int)(N + 1), s));
     hipLaunchKernelGGL((eps_walk_kernel<D, true>), dim3(blocks_for(N, 256)), dim3(256), 0, s, N, dX, d_v, d_c, P, eps, cnt,
-                       leaf_cnt, loff, d_lists, d_pt);
+                       leaf_cnt, loff, d_lists, d_pt, t.dot_mode);
     PMK_HIP(hipGetLastError());
     std::vector<int32_t> h32((size_t)std::max<int64_t>(total, 1));
     if (inds && total > 0) {
@@ -387,18 +385,18 @@ int bsp_assign_device(pmk_ctx *c, const BspArrays &t, int64_t N, const double *X
     }
 }
 
-int bsp_build_device(pmk_ctx *c, int D, int64_t N, const double *X, int levels, int sign_mode, BspArrays &t)
+int bsp_build_device(pmk_ctx *c, int D, int64_t N, const double *X, int levels, int sign_mode, int dot_mode, BspArrays &t)
 {
-    t.D = D; t.levels = levels; t.N = N;
+    t.D = D; t.levels = levels; t.N = N; t.dot_mode = dot_mode;
     t.P = (int64_t)1 << (levels - 1);
     t.v.assign((size_t)((t.P - 1) * D), 0.0);
     t.c.assign((size_t)(t.P - 1), 0.0);
     int rc;
     switch (D) {
-    case 1: rc = build_levels<1>(c, N, X, levels, sign_mode, t); break;
-    case 2: rc = build_levels<2>(c, N, X, levels, sign_mode, t); break;
-    case 3: rc = build_levels<3>(c, N, X, levels, sign_mode, t); break;
-    case 4: rc = build_levels<4>(c, N, X, levels, sign_mode, t); break;
+    case 1: rc = build_levels<1>(c, N, X, levels, sign_mode, dot_mode, t); break;
+    case 2: rc = build_levels<2>(c, N, X, levels, sign_mode, dot_mode, t); break;
+    case 3: rc = build_levels<3>(c, N, X, levels, sign_mode, dot_mode, t); break;
+    case 4: rc = build_levels<4>(c, N, X, levels, sign_mode, dot_mode, t); break;
     default: set_error("pmk_bsp_build_device: D=%d outside 1..%d", D, MAX_D); return -1;
     }
     if (rc) return rc;

@@ -213,13 +213,19 @@ __device__ __forceinline__ R kern_eval(const pmk_kernel_desc &th, const R *p, co
     else return profile<FAM, R>(th, sqrt(s));
 }
 
-// dot(u, x) as the reference's short ddot: sequential multiply-add, no FMA
+// dot(u, x) as the reference's short ddot.  mode 0: sequential multiply then add, no FMA; mode 1: a chain of
+// fused multiply-adds (what a BLAS built with contraction runs) -- see dot_seq in pmk_bsp.cpp
 template <int D>
-__device__ __forceinline__ double dot_seq(const double *u, const double *x)
+__device__ __forceinline__ double dot_seq(const double *u, const double *x, int mode)
 {
     double s = u[0] * x[0];
+    if (mode) {
 #pragma unroll
-    for (int d = 1; d < D; ++d) s = s + u[d] * x[d];
+        for (int d = 1; d < D; ++d) s = __builtin_fma(u[d], x[d], s);
+    } else {
+#pragma unroll
+        for (int d = 1; d < D; ++d) s = s + u[d] * x[d];
+    }
     return s;
 }
 

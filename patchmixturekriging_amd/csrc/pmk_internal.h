@@ -42,6 +42,7 @@ struct PatchDesc {
 // A BSP tree in heap order (root 0, children 2i+1 / 2i+2); leaves numbered left to right.
 struct BspArrays {
     int D = 0, levels = 0;
+    int dot_mode = 0;               // 0: v . x as separate multiplies and adds, 1: as a chain of fused multiply-adds
     int64_t P = 0, N = 0;
     std::vector<double> v;          // (P-1) x D heap order
     std::vector<double> c;          // P-1
@@ -97,6 +98,7 @@ struct pmk_model {
     // BSP for prediction (heap order on device)
     int levels = 0;
     int64_t P_global = 0, leaf_base = 0;
+    int dot_mode = 0;
     double *d_hv = nullptr, *d_hc = nullptr;   // heap order
     int32_t *d_pre = nullptr;                  // pre-order -> heap
     // prediction strip workspace

@@ -90,14 +90,14 @@ int launch_query_mean(const pmk_kernel_desc &th, int D, int64_t n, const double 
 #pragma clang fp contract(off)
 template <int D>
 __device__ __forceinline__ int find_leaf(const double *__restrict__ hv, const double *__restrict__ hc, int levels,
-                                         int64_t P, const double *x)
+                                         int64_t P, const double *x, int dot_mode)
 {
     int node = 0;
     for (int l = 1; l < levels; ++l) {
         double u[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) u[d] = hv[node * D + d];
-        node = (dot_seq<D>(u, x) < hc[node]) ? 2 * node + 1 : 2 * node + 2;
+        node = (dot_seq<D>(u, x, dot_mode) < hc[node]) ? 2 * node + 1 : 2 * node + 2;
     }
     return node - (int)(P - 1);
 }
@@ -110,8 +110,8 @@ constexpr int PLAN_LDS_NODES = 2047;
 template <int D, bool FILL, bool LDS>
 __global__ __launch_bounds__(256) void plan_kernel(int64_t Nq, const double *__restrict__ xq,
                                                    const double *__restrict__ hv_g, const double *__restrict__ hc_g,
-                                                   const int32_t *__restrict__ pre_g, int levels, int64_t P, double radius,
-                                                   double delta, int32_t *__restrict__ home_out,
+                                                   const int32_t *__restrict__ pre_g, int levels, int dot_mode, int64_t P,
+                                                   double radius, double delta, int32_t *__restrict__ home_out,
                                                    int32_t *__restrict__ cnt_out, const int64_t *__restrict__ qoff,
                                                    int32_t *__restrict__ item_region, double *__restrict__ item_t,
                                                    int32_t *__restrict__ item_query)
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void plan_kernel(int64_t Nq, const double *__r
     double p[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) p[d] = xq[j * D + d];
-    const int home = find_leaf<D>(hv, hc, levels, P, p);
+    const int home = find_leaf<D>(hv, hc, levels, P, p, dot_mode);
     int count = 0;
     int64_t base = 0;
     if (FILL) base = qoff[j];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void plan_kernel(int64_t Nq, const double *__r
 #pragma unroll
         for (int d = 0; d < D; ++d) u[d] = hv[h * D + d];
         const double c = hc[h];
-        const double tt = -dot_seq<D>(u, p) + c;                 // mixtureGP.jl:361
+        const double tt = -dot_seq<D>(u, p, dot_mode) + c;       // mixtureGP.jl:361
         double r0 = (p[0] + tt * u[0]) - p[0];                   // z = p + t.*u ; norm(z - p)   :362,:367
         double s = r0 * r0;
 #pragma unroll
@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void plan_kernel(int64_t Nq, const double *__r
             double z1[D], z2[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) { z1[d] = p[d] + tp * u[d]; z2[d] = p[d] + tm * u[d]; }
-            const int r1 = find_leaf<D>(hv, hc, levels, P, z1);   // :374-375
-            const int r2 = find_leaf<D>(hv, hc, levels, P, z2);
+            const int r1 = find_leaf<D>(hv, hc, levels, P, z1, dot_mode);   // :374-375
+            const int r2 = find_leaf<D>(hv, hc, levels, P, z2, dot_mode);
             if ((r2 == home) != (r1 == home)) {                   // xor :388
                 if (FILL) {
                     item_region[base + count] = (r1 == home) ? r2 : r1;
@@ -189,7 +189,7 @@ static int launch_plan_D(pmk_query *q, double radius, double delta, bool fill, h
     const size_t bytes = lds ? (size_t)nn * (D + 1) * sizeof(double) + (size_t)nn * sizeof(int32_t) : 0;
 #define PMK_PLAN(FILL_, LDS_)                                                                                          \
     hipLaunchKernelGGL((plan_kernel<D, FILL_, LDS_>), grid, dim3(256), bytes, s, q->Nq, q->d_xq, m->d_hv, m->d_hc,      \
-                       m->d_pre, m->levels, m->P_global, radius, delta, q->d_home, q->d_cnt, q->d_qoff,                \
+                       m->d_pre, m->levels, m->dot_mode, m->P_global, radius, delta, q->d_home, q->d_cnt, q->d_qoff,                \
                        q->d_item_region, q->d_item_t, q->d_item_query)
     if (fill) { if (lds) PMK_PLAN(true, true); else PMK_PLAN(true, false); }
     else      { if (lds) PMK_PLAN(false, true); else PMK_PLAN(false, false); }

@@ -95,7 +95,7 @@ def _native(root):
     return nat
 
 
-def setuppartition(X, level, sign_mode=1, device=False, ctx=None):
+def setuppartition(X, level, sign_mode=1, device=False, ctx=None, dot_mode=0):
     """setuppartition(X, level) -> root, X_parts, X_parts_inds   (partition.jl:106-129)
 
     device=True builds the tree on the GPU (pmk_bsp_build_device: same result bit for bit, for point sets where the
@@ -107,9 +107,9 @@ def setuppartition(X, level, sign_mode=1, device=False, ctx=None):
     if device:
         from .context import default_context
         ctx = ctx or default_context()
-        _lib.check(L.pmk_bsp_build_device(ctx.h, D, N, X.ctypes.data, int(level), sign_mode, C.byref(h)), "setuppartition")
+        _lib.check(L.pmk_bsp_build_device(ctx.h, D, N, X.ctypes.data, int(level), sign_mode, int(dot_mode), C.byref(h)), "setuppartition")
     else:
-        _lib.check(L.pmk_bsp_build(D, N, _d(X), int(level), sign_mode, C.byref(h)), "setuppartition")
+        _lib.check(L.pmk_bsp_build(D, N, _d(X), int(level), sign_mode, int(dot_mode), C.byref(h)), "setuppartition")
     nat = _NativeTree(h)
     P = L.pmk_bsp_num_leaves(h)
     hp_v = np.empty((P - 1, D))
@@ -123,13 +123,13 @@ def setuppartition(X, level, sign_mode=1, device=False, ctx=None):
     return root, X_parts, X_parts_inds
 
 
-def tree_from_hyperplanes(D, levels, hp_v, hp_c):
+def tree_from_hyperplanes(D, levels, hp_v, hp_c, dot_mode=0):
     """rebuild a root from its pre-order hyperplanes (to ship a tree between processes)"""
     hp_v = np.ascontiguousarray(hp_v, dtype=np.float64).reshape(-1, D)
     hp_c = np.ascontiguousarray(hp_c, dtype=np.float64)
     L = _lib.lib()
     h = C.c_void_p()
-    _lib.check(L.pmk_bsp_from_hyperplanes(D, int(levels), _d(hp_v), _d(hp_c), C.byref(h)), "pmk_bsp_from_hyperplanes")
+    _lib.check(L.pmk_bsp_from_hyperplanes(D, int(levels), _d(hp_v), _d(hp_c), int(dot_mode), C.byref(h)), "pmk_bsp_from_hyperplanes")
     return _build_nodes(_NativeTree(h), D, int(levels), hp_v, hp_c, None, None)
 
 

@@ -130,10 +130,21 @@ def jl_median(e):
     return s[n // 2] if n % 2 else s[n // 2 - 1] / 2 + s[n // 2] / 2
 
 
-def dot_seq(a, b):
+DOT_MODE = 0      # 0: dot = separate multiplies and adds; 1: a chain of fused multiply-adds (see pmk_bsp_build)
+
+
+def fma(a, b, c):
+    """correctly rounded a * b + c (exact rational arithmetic, one rounding): Python 3.10 has no math.fma"""
+    from fractions import Fraction
+    return float(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c)))
+
+
+def dot_seq(a, b, mode=None):
+    """[Julia stdlib] dot of two short vectors = BLAS ddot; `mode` as DOT_MODE (norms always use mode 0: norm is not BLAS)"""
+    mode = DOT_MODE if mode is None else mode
     s = a[0] * b[0]
     for d in range(1, len(a)):
-        s = s + a[d] * b[d]
+        s = np.float64(fma(a[d], b[d], s)) if mode else s + a[d] * b[d]
     return s
 
 
@@ -147,7 +158,7 @@ class Node:
 def gethyperplane(Xs):
     mu = jl_sum_pairwise(Xs, 0, len(Xs) - 1) / len(Xs)        # partition.jl:89
     z = Xs[0] - mu                                            # :90 first-point quirk
-    nz = np.sqrt(dot_seq(z, z))
+    nz = np.sqrt(dot_seq(z, z, 0))
     v = z / nz                                                # :92-94 (gesdd on the D x 1 parent: +)
     ev = [dot_seq(v, x) for x in Xs]                          # :69
     c = jl_median(ev)                                         # :70
@@ -201,7 +212,7 @@ def neighbours(p, radius, root, hps, home, delta):
         t = -dot_seq(u, p) + c
         z = p + t * u
         ts.append(t); keep.append(False)
-        if np.sqrt(dot_seq(z - p, z - p)) < radius:
+        if np.sqrt(dot_seq(z - p, z - p, 0)) < radius:
             r1 = findpartition(p + (t + delta) * u, root)
             r2 = findpartition(p + (t - delta) * u, root)
             if (r2 == home) != (r1 == home):
@@ -304,6 +315,10 @@ if __name__ == "__main__":
     make_mixgp()
     make_bsp("bsp_3d.npz", 3, 2048, 5, 0.05, [0, 0, 0], [1, 1, 1], 7, 400, 0.08, 1e-6)
     make_ibb1d()
+    DOT_MODE = 1      # the same restatement with dot as a chain of fused multiply-adds (small: exact rational fma is slow)
+    make_bsp("bsp_3d_fma.npz", 3, 1024, 4, 0.05, [0, 0, 0], [1, 1, 1], 9, 200, 0.08, 1e-6)
+    make_bsp("bsp_2d_fma.npz", 2, 1500, 4, 0.4, [-5, -10], [5, 10], 10, 200, 0.6, 1e-5)
+    DOT_MODE = 0
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

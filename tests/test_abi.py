@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(decl):
         assert hasattr(L, name), name
     assert decl == set(_lib.SIGNATURES), decl ^ set(_lib.SIGNATURES)
-    assert L.pmk_version() == 100
+    assert L.pmk_version() == 101
 
 
 def test_product_does_not_import_the_oracle():
@@ -47,10 +47,10 @@ def test_argument_errors_are_reported():
     L = pmk.lib()
     h = C.c_void_p()
     X = np.zeros((4, 2))
-    assert L.pmk_bsp_build(2, 4, X.ctypes.data_as(C.POINTER(C.c_double)), 1, 1, C.byref(h)) < 0   # levels >= 2
+    assert L.pmk_bsp_build(2, 4, X.ctypes.data_as(C.POINTER(C.c_double)), 1, 1, 0, C.byref(h)) < 0   # levels >= 2
     assert b"levels" in L.pmk_last_error()
-    assert L.pmk_bsp_build(2, 1, X.ctypes.data_as(C.POINTER(C.c_double)), 3, 1, C.byref(h)) < 0   # N < 2^(levels-1)
-    assert L.pmk_bsp_build(9, 4, X.ctypes.data_as(C.POINTER(C.c_double)), 2, 1, C.byref(h)) < 0   # D too large
+    assert L.pmk_bsp_build(2, 1, X.ctypes.data_as(C.POINTER(C.c_double)), 3, 1, 0, C.byref(h)) < 0   # N < 2^(levels-1)
+    assert L.pmk_bsp_build(9, 4, X.ctypes.data_as(C.POINTER(C.c_double)), 2, 1, 0, C.byref(h)) < 0   # D too large
     with pytest.raises(pmk.PmkError):
         pmk.setuppartition(np.zeros((4, 2)), 1)
     # identical points: a child node ends up empty -> reported, not crashed
@@ -58,11 +58,15 @@ def test_argument_errors_are_reported():
         pmk.setuppartition(np.zeros((64, 2)), 4)
 
 
-@pytest.mark.parametrize("name", ["bsp_2d.npz", "bsp_3d.npz"])
-def test_host_bsp_matches_golden_and_oracle(golden, name):
+@pytest.mark.parametrize("name,dot_mode", [("bsp_2d.npz", 0), ("bsp_3d.npz", 0), ("bsp_2d_fma.npz", 1), ("bsp_3d_fma.npz", 1)])
+def test_host_bsp_matches_golden_and_oracle(golden, name, dot_mode):
+    """the product's host BSP, the C oracle and the Python cross-check fixtures (tests/golden/make_golden.py) agree bit
+    for bit -- in BOTH restatements of Julia's dot (dot_mode 0: separate multiply/add, 1: fused multiply-add chain;
+    which one a Julia install runs depends on its BLAS build and cannot be pinned here)."""
     g = golden(name)
     X, levels = g["X"], int(g["levels"])
-    root, X_parts, X_parts_inds = pmk.setuppartition(X, levels)
+    root, X_parts, X_parts_inds = pmk.setuppartition(X, levels, dot_mode=dot_mode)
+    assert pmk.lib().pmk_bsp_dot_mode(pmk.partition._native(root).h) == dot_mode
     hv, hc = pmk.partition.hyperplane_arrays(root)
     assert np.array_equal(hv, g["hp_v"]) and np.array_equal(hc, g["hp_c"])
     assert np.array_equal(np.concatenate(X_parts_inds), g["leaf_inds"])
@@ -85,9 +89,43 @@ def test_host_bsp_matches_golden_and_oracle(golden, name):
         assert np.all(np.abs(d - np.abs(ts[keep])) < 1e-10)    # patchGP_partitioning.jl:214-215
     assert np.array_equal(nb_reg, g["nb_reg"]) and np.array_equal(nb_t, g["nb_t"])
     # the oracle agrees too (two independent implementations of the same arithmetic)
-    ob = O.BSP(X, levels)
+    ob = O.BSP(X, levels, dot_mode=dot_mode)
     ov, oc = ob.hyperplanes()
     assert np.array_equal(ov, hv) and np.array_equal(oc, hc)
+    assert [ob.findpartition(x) for x in g["Xq"]] == list(home)
+
+
+def test_dot_modes_differ_and_each_is_self_consistent():
+    """the two dot modes are different arithmetic (some split offsets differ in the last place) and each one is used
+    consistently by build, search, eps-assignment and neighbour search -- host library and oracle, random data"""
+    rng = np.random.Generator(np.random.PCG64(77))
+    N, levels = 30000, 7
+    X = rng.uniform(-3, 3, (N, 3))
+    q = rng.uniform(-3, 3, (300, 3))
+    trees = {}
+    for mode in (0, 1):
+        root, parts, inds = pmk.setuppartition(X, levels, dot_mode=mode)
+        ob = O.BSP(X, levels, dot_mode=mode)
+        hv, hc = pmk.partition.hyperplane_arrays(root)
+        ov, oc = ob.hyperplanes()
+        assert np.array_equal(ov, hv) and np.array_equal(oc, hc)
+        assert np.array_equal(np.concatenate(inds), ob.leaves()[1])
+        _, sinds, lists, _ = pmk.organizetrainingsets(root, levels, X, 0.07)
+        _, osinds, _, olists = ob.assign(X, 0.07)
+        assert np.array_equal(np.concatenate(sinds), osinds) and np.array_equal(np.concatenate(lists), olists)
+        hps = pmk.fetchhyperplanes(root)
+        for x in q:
+            h = pmk.findpartition(x, root)
+            assert h == ob.findpartition(x)
+            reg, ts, _, keep = pmk.findneighbourpartitions(x, 0.4, root, levels, hps, h, delta=1e-6)
+            oreg, ots, _, okeep = ob.neighbours(x, 0.4, 1e-6, h)
+            assert np.array_equal(reg, oreg) and np.array_equal(ts, ots) and np.array_equal(keep, okeep)
+        # a tree shipped through its hyperplanes keeps its mode
+        r2 = pmk.tree_from_hyperplanes(3, levels, hv, hc, dot_mode=mode)
+        assert [pmk.findpartition(x, r2) for x in q] == [pmk.findpartition(x, root) for x in q]
+        trees[mode] = hc
+    assert not np.array_equal(trees[0], trees[1])                       # different roundings somewhere ...
+    assert np.allclose(trees[0], trees[1], rtol=0, atol=1e-12)          # ... in the last places only
 
 
 def test_host_bsp_random_vs_oracle_large():

@@ -835,9 +835,9 @@ def test_device_bsp_build_is_bit_identical_to_host(D, N, levels, seed):
     pairwise-summation block, odd counts, all supported dimensions."""
     rng = np.random.Generator(np.random.PCG64(seed))
     X = rng.uniform(-5, 5, (N, D)) * np.array([1.0, 2.0, 0.5, 3.0][:D])
-    for sign_mode in (1, -1):
-        rh, Ph, Ih = pmk.setuppartition(X, levels, sign_mode=sign_mode)
-        rd, Pd, Id = pmk.setuppartition(X, levels, sign_mode=sign_mode, device=True)
+    for sign_mode, dot_mode in ((1, 0), (-1, 0), (1, 1)):
+        rh, Ph, Ih = pmk.setuppartition(X, levels, sign_mode=sign_mode, dot_mode=dot_mode)
+        rd, Pd, Id = pmk.setuppartition(X, levels, sign_mode=sign_mode, device=True, dot_mode=dot_mode)
         hh, hd = pmk.fetchhyperplanes(rh), pmk.fetchhyperplanes(rd)
         assert len(hh) == len(hd) == 2 ** (levels - 1) - 1
         for a, b in zip(hh, hd):
@@ -876,13 +876,42 @@ def test_device_eps_assignment_is_identical_to_host(D, N, levels, eps, seed):
     ascending order per leaf, regions_list_set per point in visiting order, eps = 0 included."""
     rng = np.random.Generator(np.random.PCG64(seed))
     X = rng.uniform(-5, 5, (N, D)) * np.array([1.0, 2.0, 0.5, 3.0][:D])
-    root, _, _ = pmk.setuppartition(X, levels)
-    Xh, Ih, Lh, _ = pmk.organizetrainingsets(root, levels, X, eps)
-    Xd, Id, Ld, _ = pmk.organizetrainingsets(root, levels, X, eps, device=True)
-    assert len(Ih) == len(Id)
-    for a, b in zip(Ih, Id):
-        assert np.array_equal(a, b)
-    assert np.array_equal(np.concatenate(Lh), np.concatenate(Ld))
-    assert np.array_equal([len(l) for l in Lh], [len(l) for l in Ld])
-    for a, b in zip(Xh, Xd):
-        assert np.array_equal(a, b)
+    for dot_mode in (0, 1):
+        root, _, _ = pmk.setuppartition(X, levels, dot_mode=dot_mode)
+        Xh, Ih, Lh, _ = pmk.organizetrainingsets(root, levels, X, eps)
+        Xd, Id, Ld, _ = pmk.organizetrainingsets(root, levels, X, eps, device=True)
+        assert len(Ih) == len(Id)
+        for a, b in zip(Ih, Id):
+            assert np.array_equal(a, b)
+        assert np.array_equal(np.concatenate(Lh), np.concatenate(Ld))
+        assert np.array_equal([len(l) for l in Lh], [len(l) for l in Ld])
+        for a, b in zip(Xh, Xd):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("D,dot_mode", [(2, 1), (3, 1), (3, 0)])
+def test_plan_kernel_in_both_dot_modes_vs_oracle(D, dot_mode):
+    """the query-side search (K5: home leaf, neighbour regions, t) follows the tree's dot mode: device plan against the
+    oracle built in the same mode -- bit-exact ids and t; D = 3 at levels = 12 also exercises the 74 KB LDS copy of a
+    2047-node tree (above the 64 KB default dynamic limit)"""
+    rng = np.random.Generator(np.random.PCG64(31 + D))
+    levels = 12 if D == 3 else 6
+    N = 40960 if D == 3 else 6000
+    X = rng.uniform(-1, 1, (N, D))
+    y = np.sin(X.sum(1))
+    root, X_parts, X_parts_inds = pmk.setuppartition(X, levels, dot_mode=dot_mode, device=True)
+    ob = O.BSP(X, levels, dot_mode=dot_mode)
+    th = pmk.Spline34KernelType(2.0)
+    m = pmk.DeviceModel(X_parts, [y[i] for i in X_parts_inds]); m.fit(th, 1e-3); m.set_bsp(root, 0)
+    Xq = rng.uniform(-1, 1, (3000, D))
+    radius, delta = (0.05, 1e-7) if D == 3 else (0.3, 1e-6)
+    q = pmk.DeviceQuery(m, Xq); q.plan(radius, delta)
+    dbg = q.debug()
+    for j in range(0, 3000, 3 if D == 3 else 1):
+        h = ob.findpartition(Xq[j])
+        reg, ts, _, keep = ob.neighbours(Xq[j], radius, delta, h)
+        s = slice(dbg["item_offsets"][j], dbg["item_offsets"][j + 1])
+        assert dbg["home"][j] == h and np.array_equal(dbg["item_region"][s][:-1], reg)
+        assert np.array_equal(dbg["item_t"][s][:-1], ts[keep])
+    host_home = [pmk.findpartition(x, root) for x in Xq[:500]]
+    assert np.array_equal(host_home, dbg["home"][:500])
