@@ -149,8 +149,9 @@ mutable struct BinaryNode{T}              # partition.jl:18-29
 end
 BinaryNode(data) = BinaryNode{typeof(data)}(data)
 
-# the native tree (pmk_bsp*) of every root returned by setuppartition
-const NATIVE = IdDict{Any,Ptr{Cvoid}}()
+# the native tree (pmk_bsp*) of every root returned by setuppartition.  Weak keys: the table must not keep a root
+# alive, or its finalizer (which frees the native tree) would never run.
+const NATIVE = WeakKeyDict{Any,Ptr{Cvoid}}()
 native(root) = get(NATIVE, root) do
     throw(PMKError("this node is not a root returned by setuppartition"))
 end
@@ -182,21 +183,24 @@ function buildnodes(h::Ptr{Cvoid}, D::Int, levels::Int, X)
 end
 
 """setuppartition(X, level) -> root, X_parts, X_parts_inds (src/patchwork/partition.jl:106-129);
-`device = true` builds the tree on the GPU (pmk_bsp_build_device, same result bit for bit)"""
-function setuppartition(X::Vector{Vector{T}}, level; sign_mode::Int = 1, device::Bool = false) where T
+`device = true` builds the tree on the GPU (pmk_bsp_build_device, same result bit for bit).  `sign_mode` / `dot_mode`
+select between the two readings of two Julia-stdlib behaviours the reference's text does not fix (include/pmk.h)."""
+function setuppartition(X::Vector{Vector{T}}, level; sign_mode::Int = 1, dot_mode::Int = 0, device::Bool = false) where T
     Xm = pack(X); D, N = size(Xm)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     if device
         check(ccall((:pmk_bsp_build_device, libpmk), Cint,
-            (Ptr{Cvoid}, Cint, Int64, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
-            context(), D, N, Xm, level, sign_mode, h), "setuppartition")
+            (Ptr{Cvoid}, Cint, Int64, Ptr{Float64}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}),
+            context(), D, N, Xm, level, sign_mode, dot_mode, h), "setuppartition")
     else
-        check(ccall((:pmk_bsp_build, libpmk), Cint, (Cint, Int64, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
-            D, N, Xm, level, sign_mode, h), "setuppartition")
+        check(ccall((:pmk_bsp_build, libpmk), Cint, (Cint, Int64, Ptr{Float64}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}),
+            D, N, Xm, level, sign_mode, dot_mode, h), "setuppartition")
     end
     root, off, inds = buildnodes(h[], D, Int(level), X)
     NATIVE[root] = h[]
-    finalizer(r -> (ccall((:pmk_bsp_destroy, libpmk), Cvoid, (Ptr{Cvoid},), pop!(NATIVE, r, C_NULL)); nothing), root)
+    let hh = h[]
+        finalizer(r -> (ccall((:pmk_bsp_destroy, libpmk), Cvoid, (Ptr{Cvoid},), hh); nothing), root)
+    end
     P = length(off) - 1
     X_parts_inds = [Vector{Int}(inds[off[l]+1:off[l+1]] .+ 1) for l = 1:P]
     X_parts = [Vector{Vector{Float64}}(X[ix]) for ix in X_parts_inds]      # labelleafnodes, partition.jl:131-159
@@ -213,11 +217,14 @@ function organizetrainingsets(root, levels::Int, X0::Vector{Vector{T}}, ε::T; d
     h = native(root)
     P = Int(ccall((:pmk_bsp_num_leaves, libpmk), Int64, (Ptr{Cvoid},), h))
     off = Vector{Int64}(undef, P + 1)
-    sig = (Ptr{Cvoid}, Int64, Ptr{Float64}, Float64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64})
-    dsig = (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Float64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64})
+    # (ccall wants its argument types as a literal tuple at every call site)
     assign(o, i, lo, li) = device ?
-        ccall((:pmk_bsp_assign_device, libpmk), Cint, dsig, context(), h, N, Xm, ε, o, i, lo, li) :
-        ccall((:pmk_bsp_assign, libpmk), Cint, sig, h, N, Xm, ε, o, i, lo, li)
+        ccall((:pmk_bsp_assign_device, libpmk), Cint,
+              (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Float64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+              context(), h, N, Xm, ε, o, i, lo, li) :
+        ccall((:pmk_bsp_assign, libpmk), Cint,
+              (Ptr{Cvoid}, Int64, Ptr{Float64}, Float64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+              h, N, Xm, ε, o, i, lo, li)
     check(assign(off, C_NULL, C_NULL, C_NULL), "organizetrainingsets")
     inds = Vector{Int64}(undef, max(off[end], 1)); loff = Vector{Int64}(undef, N + 1); lists = similar(inds)
     check(assign(off, inds, loff, lists), "organizetrainingsets")
@@ -375,6 +382,52 @@ function querymixtureGP!(Yq::Vector{T}, Vq::Vector{T}, Xq::Vector{Vector{T}}, η
                 push!(debug_vars.hps_keep_flags_set, keep); push!(debug_vars.zs_set, zs); push!(debug_vars.ts_set, ts)
             end
         end
+    finally
+        ccall((:pmk_query_destroy, libpmk), Cvoid, (Ptr{Cvoid},), q[])
+    end
+    return nothing
+end
+
+# ------------------------------------------------------------------------------------------ multi-GPU (one process per GPU)
+"""Comm(rank, world, id): the library's own RCCL communicator (pmk_comm_create; collective).  Rank 0 makes `id` with
+`comm_unique_id()` and ships the 128 bytes to the other ranks by any host channel (MPI.jl's `MPI.Bcast!`, a file ...)."""
+mutable struct Comm
+    h::Ptr{Cvoid}
+    rank::Int
+    world::Int
+end
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:pmk_comm_unique_id, libpmk), Cint, (Ptr{UInt8},), id), "pmk_comm_unique_id")
+    return id
+end
+function Comm(rank::Integer, world::Integer, id::Vector{UInt8})
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pmk_comm_create, libpmk), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
+                context(), rank, world, id, h), "pmk_comm_create")
+    c = Comm(h[], rank, world)
+    finalizer(x -> (ccall((:pmk_comm_destroy, libpmk), Cvoid, (Ptr{Cvoid},), x.h); nothing), c)
+    return c
+end
+
+"""querymixtureGP!(Yq, Vq, Xq_local, η_local, comm, root, levels, radius, δ, θ, σ², weight_θ): the sharded form of
+querymixtureGP! (mixtureGP.jl:159-294).  This rank's `η_local` holds the leaves `rank*P/world+1 : (rank+1)*P/world` of the
+replicated tree `root` (fit them with fitmixtureGP! on `X_set[that range]`), `Xq_local` is this rank's share of the
+queries; requests travel to the leaf owners and (u, v) back over RCCL inside the library (pmk_query_predict_sharded)."""
+function querymixtureGP!(Yq::Vector{T}, Vq::Vector{T}, Xq::Vector{Vector{T}}, η::MixtureGPType{T}, comm::Comm, root, levels,
+                         radius::T, δ::T, θ, σ², weight_θ)::Nothing where T
+    η.model == C_NULL && throw(PMKError("fitmixtureGP! must run before querymixtureGP!"))
+    Nq = length(Xq); Xm = pack(Xq)
+    resize!(Yq, Nq); resize!(Vq, Nq)
+    P = Int(ccall((:pmk_model_num_patches, libpmk), Int64, (Ptr{Cvoid},), η.model))
+    check(ccall((:pmk_model_set_bsp, libpmk), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), η.model, native(root), comm.rank * P), "pmk_model_set_bsp")
+    q = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pmk_query_create, libpmk), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ref{Ptr{Cvoid}}), η.model, Nq, Xm, q), "pmk_query_create")
+    try
+        check(ccall((:pmk_query_predict_sharded, libpmk), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ref{KernelDesc}, Ref{KernelDesc}, Float64, Float64, Ptr{Int64}),
+            q[], comm.h, Ref(desc(θ)), Ref(desc(weight_θ)), radius, δ, C_NULL), "pmk_query_predict_sharded")
+        check(ccall((:pmk_query_fetch, libpmk), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), q[], Yq, Vq), "pmk_query_fetch")
     finally
         ccall((:pmk_query_destroy, libpmk), Cvoid, (Ptr{Cvoid},), q[])
     end
