@@ -28,6 +28,10 @@ int pmk_selftest_mfma_peak(pmk_ctx *ctx, double *tflops);
  * (the rank then sends to itself through RCCL): the only way to drive that path on a one-GPU box */
 int pmk_test_comm_force_exchange(pmk_comm *comm, int on);
 
+/* choose the factorisation path of a model by hand: 0 = one workgroup per block row (batched), 1 = split path (deep
+ * products cut along K, block-wise triangular solves); pmk_model_create picks by itself from P and the tile counts */
+int pmk_test_model_set_split(pmk_model *model, int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,7 @@ SIGNATURES = {
     "pmk_selftest_trisolve": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "pmk_selftest_mfma_peak": (C.c_int, [_vp, _dp]),
     "pmk_test_comm_force_exchange": (C.c_int, [_vp, C.c_int]),
+    "pmk_test_model_set_split": (C.c_int, [_vp, C.c_int]),
 }
 
 

@@ -397,7 +397,7 @@ void pmk_model_destroy(pmk_model *m)
     if (!m) return;
     dev_free(m->d_desc); dev_free(m->d_info); dev_free(m->d_hv); dev_free(m->d_hc); dev_free(m->d_pre);
     dev_free(m->d_order);
-    for (void **p : {&m->d_x, &m->d_y, &m->d_z, &m->d_c, &m->d_a, &m->d_inv, &m->d_strip}) {
+    for (void **p : {&m->d_x, &m->d_y, &m->d_z, &m->d_c, &m->d_a, &m->d_inv, &m->d_strip, &m->d_partial, &m->d_solve_part}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -477,6 +477,10 @@ int pmk_model_create_ex(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const 
         for (int64_t r = 0; r < P; ++r) order[(size_t)r] = (int32_t)r;
         std::stable_sort(order.begin(), order.end(),
                          [&](int32_t a2, int32_t b2) { return m->desc[(size_t)a2].nt > m->desc[(size_t)b2].nt; });
+        // one workgroup per block row fills the chip only if there are enough patches: P (max_nt - 1) / 2 block rows per
+        // step on average against two workgroups per CU.  Below that -- single large problems, fitRKHS! at scale -- the
+        // factorisation takes the split path (pmk_chol.hip).
+        m->split_mode = m->max_nt >= 8 && P * (int64_t)(m->max_nt - 1) / 2 < 2 * (int64_t)ctx->num_cu;
         m->active_prefix.assign((size_t)m->max_nt + 2, 0);
         for (int64_t r = 0; r < P; ++r)
             for (int t = 0; t <= m->desc[(size_t)r].nt; ++t) ++m->active_prefix[(size_t)t];
@@ -518,6 +522,14 @@ int pmk_model_set_targets(pmk_model *m, const double *const *y)
     PMK_HIP(hipStreamSynchronize(m->ctx->stream));
     m->fitted = false;
     return upload_targets(m, y);
+}
+
+/* include/pmk_test.h: force the factorisation path of a model (tests compare the two on the same data) */
+int pmk_test_model_set_split(pmk_model *m, int on)
+{
+    if (!m) { set_error("pmk_test_model_set_split: model is NULL"); return -1; }
+    m->split_mode = on != 0 && m->max_nt >= 2;
+    return 0;
 }
 
 int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)

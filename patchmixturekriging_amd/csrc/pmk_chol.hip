@@ -46,6 +46,7 @@ constexpr int POTRF_RHS = POTRF_COL + TILE + 8;             // [2*TILE]
 constexpr int POTRF_SDIAG = POTRF_RHS + 2 * TILE;           // [1]
 constexpr int POTRF_BAD = POTRF_SDIAG + 2;                  // int
 constexpr int POTRF_END = POTRF_BAD + 2;
+constexpr int PARTIAL_TILE = TILE * TILE / 2;      // a 128 x 128 partial product tile in real2 units
 static_assert(POTRF_END <= TRI_LDS_DOUBLES, "potrf scratch must fit into the TRSM operand array");
 
 // ---------------------------------------------------------------------------------------------
@@ -201,11 +202,17 @@ __global__ __launch_bounds__(256, 2) void chol_first_kernel(const PatchDesc *__r
 // in the GEMM + TRSM part the waves are independent (no barrier after the operand staging) and two workgroups
 // share a CU (2 waves per SIMD).
 // ---------------------------------------------------------------------------------------------
+// SPLIT > 0 (single large problems, P too small to fill the chip with one workgroup per block row): the deep GEMMs
+// were done by chol_partial_kernel, SPLIT-way split along K, and left as partial tiles; this kernel then adds them up,
+// applies block column k itself (128 deep) and carries on as above -- except that the forward-solve right-hand side is
+// not carried along (z comes from the separate solve sweeps of that path).
+template <int SPLIT>
 __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__restrict__ descs,
                                                            const int32_t *__restrict__ order, int nactive, int G,
                                                            int launch, int max_nt, real *__restrict__ A,
                                                            real *__restrict__ ninv, const real *__restrict__ y,
-                                                           real *__restrict__ z, int32_t *__restrict__ info)
+                                                           real *__restrict__ z, int32_t *__restrict__ info,
+                                                           const real2_t *__restrict__ partial, int nsplit)
 {
     __shared__ real lds[TRI_LDS_DOUBLES];
     // (patch slot, block row) from the hardware block id.  Blocks are dealt round-robin over the 8 XCDs (block b runs on
@@ -213,13 +220,23 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
     // evenly) and ALL block rows of those patches -- they stream the same block row k of L, which that XCD's L2 then
     // fetches once.  Within an XCD the critical workgroups (bx == 0) have the lowest ids: they are dispatched first.
     // The grid is padded to 8 x ceil(nactive / 8) x G; the surplus workgroups of the short XCDs exit here.
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int per = (nactive - xcd + 7) >> 3;             // patch slots of this XCD
-    if (idx >= per * G) return;
-    int loc, bx;
-    if (idx < per) { loc = idx; bx = 0; }
-    else { const int j = idx - per; loc = j / (G - 1); bx = 1 + j % (G - 1); }
-    const int slot = xcd + 8 * loc;
+    int slot, bx;
+    if (SPLIT) {
+        // few patches: their block rows are dealt over ALL XCDs (one XCD per patch would leave most of the chip idle);
+        // critical workgroups first
+        const int lid = blockIdx.x;
+        if (lid >= nactive * G) return;
+        if (lid < nactive) { slot = lid; bx = 0; }
+        else { const int j = lid - nactive; slot = j / (G - 1); bx = 1 + j % (G - 1); }
+    } else {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int per = (nactive - xcd + 7) >> 3;             // patch slots of this XCD
+        if (idx >= per * G) return;
+        int loc;
+        if (idx < per) { loc = idx; bx = 0; }
+        else { const int j = idx - per; loc = j / (G - 1); bx = 1 + j % (G - 1); }
+        slot = xcd + 8 * loc;
+    }
     const int pid = order[slot];
     const PatchDesc pd = descs[pid];
     const int k = launch - (max_nt - pd.nt);      // this patch's block column (end-aligned schedule): 0 <= k < nt - 1
@@ -275,7 +292,19 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
                     acc.f[fi][0][q] = -acc.f[fi][0][q];
                     acc.f[fi][1][q] = -acc.f[fi][1][q];
                 }
-            if (k > 0) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
+            if (SPLIT) {
+                // tile bx of this patch's G + 1 tiles: the partial products L[rows, Kc] L[k, Kc]^T of the K chunks
+                const real2_t *pt = partial + (((int64_t)slot * (G + 1) + bx) * nsplit) * PARTIAL_TILE + wave * (PARTIAL_TILE / 4) + lane;
+                for (int sp = 0; sp < nsplit; ++sp, pt += PARTIAL_TILE)
+#pragma unroll
+                    for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const real2_t v = pt[(fi * 4 + q) * 64];
+                            acc.f[fi][0][q] += v[0];
+                            acc.f[fi][1][q] += v[1];
+                        }
+            } else if (k > 0) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
             // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
             tri_solve_inplace<1>(acc, lds, lane);
 #pragma unroll
@@ -307,7 +336,42 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
     const int K2 = (k + 1) * TILE;                    // block columns 0..k
     const int h = wave >> 1, g = wave & 1;            // 64-row half, 64-column half of the tile
     real *Att = S + t0 + t0 * ld;
-    if (!(h == 0 && g == 1)) {
+    if (SPLIT) {
+        // the look-ahead tile arrives as partial products too (tile index G, block columns 0..k-1); block column k --
+        // made above -- is applied here.  All four waves, 32 rows x 128 columns each: the part above the diagonal is
+        // computed along (never read by anyone: the potrf below takes the lower triangle only).
+        WaveTile<4, 1> acc;
+        real *outl = Att + 32 * wave + 2 * (lane & 15);
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const real2_t a = *reinterpret_cast<const real2_t *>(outl + tile_i(fi, lane, q) * ld);
+                acc.f[fi][0][q] = -a[0];
+                acc.f[fi][1][q] = -a[1];
+            }
+        const real2_t *pt = partial + (((int64_t)slot * (G + 1) + G) * nsplit) * PARTIAL_TILE + wave * (PARTIAL_TILE / 4) + lane;
+        for (int sp = 0; sp < nsplit; ++sp, pt += PARTIAL_TILE)
+#pragma unroll
+            for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const real2_t v = pt[(fi * 4 + q) * 64];
+                    acc.f[fi][0][q] += v[0];
+                    acc.f[fi][1][q] += v[1];
+                }
+        gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + t0 + c0 * ld, ld, S + t0 + 32 * wave + c0 * ld, ld, TILE, lane);
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                real2_t o;
+                o[0] = -acc.f[fi][0][q];
+                o[1] = -acc.f[fi][1][q];
+                *reinterpret_cast<real2_t *>(outl + tile_i(fi, lane, q) * ld) = o;
+            }
+        if (tid < TILE) lds[POTRF_RHS + tid] = (real)0;
+    } else if (!(h == 0 && g == 1)) {
         // A[k+1,k+1] -= L[k+1,0:k+1] L[k+1,0:k+1]^T, lower 64 x 64 sub-tiles: acc = -A up-front (all the sub-tile's
         // loads in flight at once), the GEMM adds L L^T, the store negates
         WaveTile<2, 2> acc;
@@ -361,6 +425,177 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
     PMK_STAMP(4);
     tile_potrf(Att, ld, lds, ninv + pd.ioff + (int64_t)(k + 1) * (4 * SB * SB), z + pd.yoff + t0, info + pid, k + 1);
     PMK_STAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-K path (single large problems: SURVEY section 8(f) rank 3).  With few patches the left-looking step has only
+// nt - k - 1 workgroups, each with a GEMM of depth 128 k, and a critical workgroup whose look-ahead is as deep: the
+// chip idles and the factorisation is chain-bound.  chol_partial_kernel cuts every deep product of a step -- the G
+// block rows AND the look-ahead tile -- into `nsplit` chunks along K, one workgroup each (a 2-D tiling of the step:
+// tiles x K chunks), and writes the partial tiles; chol_step_kernel<1> sums them.  Tile layout in memory = the
+// accumulator layout ([wave][fragment][register][lane] pairs), so stores and loads are 1 KB coalesced per wave.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void chol_partial_kernel(const PatchDesc *__restrict__ descs,
+                                                              const int32_t *__restrict__ order, int nactive, int G,
+                                                              int nsplit, int launch, int max_nt, const real *__restrict__ A,
+                                                              real2_t *__restrict__ partial)
+{
+    // (patch slot, tile, K chunk) straight from the block id: consecutive blocks = the chunks of one tile, then the next
+    // tile of the same patch -- spread over all XCDs (this path exists because there are too few patches to fill them)
+    const int tiles = G + 1;
+    const int idx = blockIdx.x;
+    const int slot = idx / (tiles * nsplit), rem = idx - slot * (tiles * nsplit);
+    const int t = rem / nsplit, sp = rem - t * nsplit;
+    const PatchDesc pd = descs[order[slot]];
+    const int k = launch - (max_nt - pd.nt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const real *S = A + pd.aoff;
+    const int64_t ld = pd.ld;
+    const int chunk = (k + nsplit - 1) / nsplit;              // block columns per chunk
+    const int kb = sp * chunk, ke = min(k, kb + chunk);
+    const int64_t rI = (int64_t)(t < G ? k : k + 1) * TILE;                      // I rows: block row k, or k + 1 (look-ahead)
+    const int64_t rJ = (int64_t)(t < G ? k + 1 + t : k + 1) * TILE + 32 * wave;  // J rows of this wave
+    WaveTile<4, 1> acc;
+    acc.zero();
+    if (ke > kb && rJ < pd.n)
+        gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + rI + (int64_t)kb * TILE * ld, ld, S + rJ + (int64_t)kb * TILE * ld, ld,
+                                         (ke - kb) * TILE, lane);
+    real2_t *out = partial + (((int64_t)slot * tiles + t) * nsplit + sp) * PARTIAL_TILE + wave * (PARTIAL_TILE / 4) + lane;
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            real2_t o;
+            o[0] = acc.f[fi][0][q];
+            o[1] = acc.f[fi][1][q];
+            out[(fi * 4 + q) * 64] = o;
+        }
+}
+
+// The two triangular solves of the split path, block by block, two launches per block:
+//   solve_partial_kernel<DIR> : the long matrix-vector product of block k cut into chunks, one workgroup each
+//       DIR = +1 (z = L^-1 y):  p[chunk][row] = sum_{c in chunk of [0, 128 k)}     L[128 k + row, c] z[c]
+//       DIR = -1 (c = L^-T z):  p[chunk][col] = sum_{i in chunk of [128 (k+1), ld)} L[i, 128 k + col] c[i]
+//   solve_block_kernel<DIR>   : v = rhs_k - sum of the chunks (fixed order: deterministic), then the 128 x 128 diagonal
+//       solve by block substitution with the staged 32 x 32 blocks (off-diagonal blocks of L[kk], -D^-1 blocks).
+// Block index of a patch at launch j: k = j (forward), k = nt - 1 - j (backward); shorter patches sit out.
+template <int DIR>
+__global__ __launch_bounds__(256) void solve_partial_kernel(const PatchDesc *__restrict__ descs, int j, int nchunk,
+                                                            const real *__restrict__ A, const real *__restrict__ vec,
+                                                            real *__restrict__ part)
+{
+    const PatchDesc pd = descs[blockIdx.y];
+    if (j >= pd.nt) return;
+    const int k = DIR > 0 ? j : pd.nt - 1 - j;
+    const int ch = blockIdx.x;
+    const real *S = A + pd.aoff;
+    const int64_t ld = pd.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    real *out = part + ((int64_t)blockIdx.y * nchunk + ch) * TILE;
+    __shared__ real red[2 * TILE];
+    if (DIR > 0) {
+        const int64_t span = (int64_t)k * TILE;
+        const int64_t per = ((span + nchunk - 1) / nchunk + 15) & ~(int64_t)15;
+        const int64_t cb = ch * per, ce = min(span, cb + per);
+        const int row = tid & 127, hf = tid >> 7;
+        const real *Lr = S + (int64_t)k * TILE + row;
+        const real *zz = vec + pd.yoff;
+        real s0 = 0, s1 = 0;
+        for (int64_t c = cb + 8 * hf; c < ce; c += 16) {       // each half takes alternate groups of 8 columns (chunks are
+            real lv[8];                                         // multiples of 16 columns)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lv[u] = Lr[(c + u) * ld];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { s0 += lv[u] * zz[c + u]; s1 += lv[u + 1] * zz[c + u + 1]; }
+        }
+        red[tid] = s0 + s1;
+        __syncthreads();
+        if (tid < TILE) out[tid] = red[tid] + red[tid + TILE];
+    } else {
+        const int64_t i0 = (int64_t)(k + 1) * TILE, span = ld - i0;
+        const int64_t per = ((span + nchunk - 1) / nchunk + 63) & ~(int64_t)63;
+        const int64_t ib = i0 + ch * per, ie = min((int64_t)ld, ib + per);
+        const real *cs = vec + pd.yoff;
+        for (int cc = wave; cc < TILE; cc += 4) {               // one wave per column, coalesced rows
+            const real *col = S + ((int64_t)k * TILE + cc) * ld;
+            real s0 = 0, s1 = 0;
+            int64_t i = ib + lane;
+            for (; i + 64 < ie; i += 128) { s0 += col[i] * cs[i]; s1 += col[i + 64] * cs[i + 64]; }
+            for (; i < ie; i += 64) s0 += col[i] * cs[i];
+            real s = s0 + s1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) out[cc] = s;
+        }
+    }
+}
+
+template <int DIR>
+__global__ __launch_bounds__(256) void solve_block_kernel(const PatchDesc *__restrict__ descs, int j, int nchunk,
+                                                          const real *__restrict__ A, const real *__restrict__ ninv,
+                                                          const real *__restrict__ rhs, const real *__restrict__ part,
+                                                          real *__restrict__ sol)
+{
+    const PatchDesc pd = descs[blockIdx.x];
+    if (j >= pd.nt) return;
+    const int k = DIR > 0 ? j : pd.nt - 1 - j;
+    __shared__ real tri[TRI_LDS_DOUBLES];
+    __shared__ real v[TILE], w[TILE];
+    const int tid = threadIdx.x;
+    const real *S = A + pd.aoff;
+    const int64_t ld = pd.ld, d0 = (int64_t)k * TILE;
+    stage_tri_operands(tri, S + d0 + d0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
+    if (tid < TILE) {
+        real acc = rhs[pd.yoff + d0 + tid];
+        const bool any = DIR > 0 ? k > 0 : k + 1 < pd.nt;
+        if (any)
+            for (int c = 0; c < nchunk; ++c) acc -= part[((int64_t)blockIdx.x * nchunk + c) * TILE + tid];
+        v[tid] = acc;
+    }
+    __syncthreads();
+    const int sb = tid >> 5, i = tid & 31;          // threads 0..127: block sb, entry i
+    if (DIR > 0) {
+        // z_s = -Ninv_s (v_s - sum_{jb<s} L[s][jb] z_jb)
+        for (int s2 = 0; s2 < 4; ++s2) {
+            if (tid < TILE && sb == s2) {
+                real t = v[32 * s2 + i];
+                for (int jb = 0; jb < s2; ++jb) {
+                    const real *blk = tri + 1024 * (s2 * (s2 - 1) / 2 + jb);
+                    for (int c = 0; c < SB; ++c) t -= blk[i + 32 * c] * w[32 * jb + c];
+                }
+                v[32 * s2 + i] = t;
+            }
+            __syncthreads();
+            if (tid < TILE && sb == s2) {
+                const real *nb = tri + 1024 * (6 + s2);
+                real t = 0;
+                for (int c = 0; c <= i; ++c) t -= nb[i + 32 * c] * v[32 * s2 + c];      // -Ninv = L_ss^-1 (lower)
+                w[32 * s2 + i] = t;
+            }
+            __syncthreads();
+        }
+    } else {
+        // c_s = -Ninv_s^T (v_s - sum_{jb>s} L[jb][s]^T c_jb)
+        for (int s2 = 3; s2 >= 0; --s2) {
+            if (tid < TILE && sb == s2) {
+                real t = v[32 * s2 + i];
+                for (int jb = s2 + 1; jb < 4; ++jb) {
+                    const real *blk = tri + 1024 * (jb * (jb - 1) / 2 + s2) + 32 * i;     // column i of block (jb, s2)
+                    for (int r = 0; r < SB; ++r) t -= blk[r] * w[32 * jb + r];
+                }
+                v[32 * s2 + i] = t;
+            }
+            __syncthreads();
+            if (tid < TILE && sb == s2) {
+                const real *nb = tri + 1024 * (6 + s2) + 32 * i;                           // column i of Ninv_s
+                real t = 0;
+                for (int r = i; r < SB; ++r) t -= nb[r] * v[32 * s2 + r];
+                w[32 * s2 + i] = t;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < TILE) sol[pd.yoff + d0 + tid] = w[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -461,6 +696,24 @@ __global__ __launch_bounds__(1024) void chol_backsolve_kernel(const PatchDesc *_
         for (int i = tid; i < pd.ld; i += 1024) cvec[pd.yoff + i] = cs[i];
 }
 
+// workspace of the split path, grow only
+static int reserve_split(pmk_model *m, size_t partial_bytes, size_t solve_bytes)
+{
+    if (partial_bytes > m->partial_bytes) {
+        if (m->d_partial) PMK_HIP(hipFree(m->d_partial));
+        m->d_partial = nullptr; m->partial_bytes = 0;
+        PMK_HIP(hipMalloc(&m->d_partial, partial_bytes));
+        m->partial_bytes = partial_bytes;
+    }
+    if (solve_bytes > m->solve_bytes) {
+        if (m->d_solve_part) PMK_HIP(hipFree(m->d_solve_part));
+        m->d_solve_part = nullptr; m->solve_bytes = 0;
+        PMK_HIP(hipMalloc(&m->d_solve_part, solve_bytes));
+        m->solve_bytes = solve_bytes;
+    }
+    return 0;
+}
+
 int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 {
     // gemm_nt consumes K in groups of 4*PF k-indices; K is always a multiple of TILE here
@@ -473,6 +726,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
     hipLaunchKernelGGL(chol_first_kernel, dim3((unsigned)np), dim3(256), 0, s, m->d_desc, (real *)m->d_a, (real *)m->d_inv,
                        (const real *)m->d_y, (real *)m->d_z, m->d_info);
     const bool fine = c->timers >= 2;
+    const int want_wg = 2 * c->num_cu;                     // workgroups that fill the chip (two per CU)
     for (int l = 0; l + 1 < m->max_nt; ++l) {
         // patches with nt >= max_nt - l are active: a prefix of `order` (sorted by nt, largest first)
         const int nactive = m->active_prefix[(size_t)(m->max_nt - l)];
@@ -486,11 +740,65 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
             }
             PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].first, s));
         }
-        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(8 * ((nactive + 7) / 8) * G)), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
-                           m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info);
+        // split path: K chunks so that tiles x chunks fills the chip; a chunk is at least two block columns deep
+        int nsplit = 1;
+        if (m->split_mode && l >= 4) {
+            const int tiles = nactive * (G + 1);
+            nsplit = std::min(std::min(16, l / 2), (want_wg + tiles - 1) / tiles);   // 64-way: the serial sum in the combine costs more than it buys
+            nsplit = std::max(nsplit, 1);
+        }
+        const unsigned grid = (unsigned)(8 * ((nactive + 7) / 8) * G);
+        if (nsplit > 1) {
+            const int tiles = G + 1;
+            const size_t bytes = sizeof(real2_t) * (size_t)PARTIAL_TILE * (size_t)nactive * tiles * nsplit;
+            if (int rc = reserve_split(m, bytes, 0)) return rc;
+            hipLaunchKernelGGL(chol_partial_kernel, dim3((unsigned)(nactive * tiles * nsplit)), dim3(256), 0, s,
+                               m->d_desc, m->d_order, nactive, G, nsplit, l, m->max_nt, (const real *)m->d_a,
+                               (real2_t *)m->d_partial);
+            hipLaunchKernelGGL(chol_step_kernel<1>, dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
+                               m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,
+                               (const real2_t *)m->d_partial, nsplit);
+        } else {
+            hipLaunchKernelGGL(chol_step_kernel<0>, dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
+                               m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,
+                               (const real2_t *)nullptr, 1);
+        }
         if (fine) {
             PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].second, s));
             c->panel_n = l + 1;
+        }
+    }
+    PMK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the two triangular solves of the split path: z = L^-1 y, then c = L^-T z, block by block with the long products cut
+// into chunks (see solve_partial_kernel)
+static int launch_split_solves(pmk_model *m, hipStream_t s)
+{
+    const int P = (int)m->P;
+    const int max_chunks = std::max(1, std::min(256, 2 * m->ctx->num_cu / P));
+    if (int rc = reserve_split(m, 0, sizeof(real) * (size_t)P * max_chunks * TILE)) return rc;
+    real *part = (real *)m->d_solve_part;
+    for (int dir = 0; dir < 2; ++dir) {
+        const real *rhs = dir == 0 ? (const real *)m->d_y : (const real *)m->d_z;
+        real *sol = dir == 0 ? (real *)m->d_z : (real *)m->d_c;
+        for (int j = 0; j < m->max_nt; ++j) {
+            const int nchunk = std::max(1, std::min(max_chunks, j * TILE / 256));
+            if (j > 0) {
+                if (dir == 0)
+                    hipLaunchKernelGGL(solve_partial_kernel<1>, dim3((unsigned)nchunk, (unsigned)P), dim3(256), 0, s, m->d_desc, j,
+                                       nchunk, (const real *)m->d_a, (const real *)sol, part);
+                else
+                    hipLaunchKernelGGL(solve_partial_kernel<-1>, dim3((unsigned)nchunk, (unsigned)P), dim3(256), 0, s, m->d_desc, j,
+                                       nchunk, (const real *)m->d_a, (const real *)sol, part);
+            }
+            if (dir == 0)
+                hipLaunchKernelGGL(solve_block_kernel<1>, dim3((unsigned)P), dim3(256), 0, s, m->d_desc, j, nchunk,
+                                   (const real *)m->d_a, (const real *)m->d_inv, rhs, part, sol);
+            else
+                hipLaunchKernelGGL(solve_block_kernel<-1>, dim3((unsigned)P), dim3(256), 0, s, m->d_desc, j, nchunk,
+                                   (const real *)m->d_a, (const real *)m->d_inv, rhs, part, sol);
         }
     }
     PMK_HIP(hipGetLastError());
@@ -547,6 +855,7 @@ int set_device_attributes()
 
 int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 {
+    if (m->split_mode) return launch_split_solves(m, s);
     const size_t fixed = sizeof(real) * (TILE + 10 * SB * (SB + 1));
     const size_t csb = sizeof(real) * (size_t)m->max_nt * TILE;
     const int cs_in_lds = fixed + csb <= 150 * 1024;

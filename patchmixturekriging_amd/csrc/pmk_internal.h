@@ -91,6 +91,11 @@ struct pmk_model {
     // patches have nt >= t (the active prefix of `order` at launch max_nt - t of the end-aligned schedule)
     int32_t *d_order = nullptr;
     std::vector<int32_t> active_prefix;
+    // split path (few, large patches: the deep products of a step are cut along K over several workgroups and the two
+    // triangular solves run block by block over many workgroups): chosen at creation from P and the tile counts
+    bool split_mode = false;
+    void *d_partial = nullptr; size_t partial_bytes = 0;      // partial product tiles of one step
+    void *d_solve_part = nullptr; size_t solve_bytes = 0;     // partial matrix-vector products of one solve block
     int64_t tot_a = 0, tot_x = 0, tot_y = 0, tot_inv = 0;
     bool fitted = false;
     pmk_kernel_desc th{};

@@ -803,6 +803,41 @@ def test_config_E_fp32_full_size_against_fp64_device_model():
     assert np.all(V32 >= 1e-12) and np.all(V32 <= 1 + 1e-6)
 
 
+# ------------------------------------------------------------------------------------ single large problem
+@pytest.mark.parametrize("P,n,D", [(1, 8192, 3), (3, 3000, 2), (2, 1111, 2)])
+def test_split_path_matches_batched_path_and_lapack(P, n, D):
+    """few, large patches: the split path (chol_partial_kernel + chol_step_kernel<1> + block-wise solve sweeps) against
+    the batched path on the same data (forced either way through include/pmk_test.h) and against LAPACK on the
+    oracle's kernel matrix; ragged sizes included (the second case runs patches of 3000, 2744 and 2488 points)"""
+    import scipy.linalg as sla
+    rng = np.random.Generator(np.random.PCG64(100 + n))
+    sizes = [n - 256 * r for r in range(P)]
+    Xs = [rng.uniform(0, 1, (m, D)) for m in sizes]
+    ys = [np.sin(3 * x[:, 0]) + x[:, -1] ** 2 for x in Xs]
+    a, sigma2 = (6.0, 1e-4) if D == 3 else (3.0, 1e-5)
+    th, oth = pmk.Spline34KernelType(a), O.kernel(O.SPLINE34, a)
+    ctx = pmk.default_context()
+    out = {}
+    for split in (0, 1):
+        m = pmk.DeviceModel(Xs, ys)
+        assert ctx.L.pmk_test_model_set_split(m.h, split) == 0
+        m.fit(th, sigma2)
+        assert np.all(m.info() == 0)
+        out[split] = [(m.get(r, M.GET_L), m.get(r, M.GET_C)) for r in range(P)]
+    for r in range(P):
+        (L0, c0), (L1, c1) = out[0][r], out[1][r]
+        U = O.kernel_matrix(oth, Xs[r]) + sigma2 * np.eye(sizes[r])
+        Lref = sla.cholesky(U, lower=True, check_finite=False)
+        for L, c in ((L0, c0), (L1, c1)):
+            assert np.abs(L - Lref).max() < 1e-9
+            assert np.linalg.norm(U @ c - ys[r]) / (np.linalg.norm(U) * np.linalg.norm(c) + np.linalg.norm(ys[r])) <= 1e-13
+        assert np.abs(L1 - L0).max() < 1e-11                       # same tiles, other summation order
+        assert np.linalg.norm(c1 - c0) / np.linalg.norm(c0) < 1e-7  # ~ cond(U) eps
+    # what pmk_model_create chooses by itself for so few patches (P (nt - 1) / 2 block rows per step << 2 per CU): split
+    auto = pmk.DeviceModel(Xs, ys); auto.fit(th, sigma2)
+    assert np.array_equal(auto.get(0, M.GET_C), out[1][0][1])
+
+
 def test_config_A_ibb1d_n512():
     """BASELINE config A: IBB1D.jl scaled to N = 512, single patch, BrownianBridge10, sigma2 = 1e-5
     (examples/IBB1D.jl:19-62) -- GPU path against the oracle's fitRKHS! / query!."""
