@@ -168,6 +168,13 @@ int  pmk_model_load(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const doub
  * mu[j] = k(xq_j, X).c,  var[j] = clamp(k(xq_j,xq_j) - |L^-1 k(xq_j, X)|^2, 1e-12, inf).  No tree needed. */
 int  pmk_model_queryinner(pmk_model *m, int64_t patch, const pmk_kernel_desc *th, int64_t Nq, const double *Xq,
                           double *mu, double *var);
+/* the same with the keyword min_v of queryinner! (mixtureGP.jl:296): var = max(k(x,x) - |L^-1 k|^2, min_v).  min_v =
+ * -HUGE_VAL gives the unclamped variance term1 - term2 of evalqueryGP! (src/RKHS/querying.jl:61-79) */
+int  pmk_model_queryinner_ex(pmk_model *m, int64_t patch, const pmk_kernel_desc *th, int64_t Nq, const double *Xq,
+                             double min_v, double *mu, double *var);
+/* replace the resident weights c_set (setupGPquery(c, X, theta, sigma2), querying.jl:43-59, takes c from its caller:
+ * fit for the factor of K + sigma2 I, then put the caller's c in place) */
+int  pmk_model_set_weights(pmk_model *m, const double *const *c);
 
 /* ---- predict -------------------------------------------------------------------------- */
 /* attach the tree; this model holds the global leaves [leaf_base, leaf_base + P) */
@@ -234,6 +241,9 @@ int  pmk_predict_mixture(pmk_model *m, const pmk_kernel_desc *th, const pmk_kern
 /* query!(Yq, Xq, eta)  src/RKHS/RKHS.jl:220-247 : mean only, Yq = K(Xq, X) c */
 int  pmk_query_mean(pmk_ctx *ctx, const pmk_kernel_desc *th, int D, int64_t n, const double *X,
                     const double *c, int64_t Nq, const double *Xq, double *Yq);
+/* query!(Yq, Xq, eta::RKHSProblemType{Vector{KT}})  RKHS.jl:278-305 : one kernel per centre, ths[n] */
+int  pmk_query_mean_multi(pmk_ctx *ctx, const pmk_kernel_desc *ths, int D, int64_t n, const double *X,
+                          const double *c, int64_t Nq, const double *Xq, double *Yq);
 
 #ifdef __cplusplus
 }

@@ -8,9 +8,9 @@ fallback -- without the library the operators raise.
 """
 from ._lib import PmkError, build, lib                                              # noqa: F401
 from .context import Comm, Context, comm_unique_id, default_context, set_device, shard_segments                            # noqa: F401
-from .kernels import (BrownianBridge10, BrownianBridge1eps, BrownianBridge20,        # noqa: F401
+from .kernels import (AdaptiveKernelMultiWarpType, AdaptiveKernelType, BrownianBridge10, BrownianBridge1eps, BrownianBridge20,        # noqa: F401
                       BrownianBridge2eps, BrownianBridgeKernelType, BrownianBridgeSemiInfDomain,
-                      GaussianKernel1DType, ModulatedSqExpKernelType, RationalQuadraticKernelType,
+                      FastAdaptiveKernelType, GaussianKernel1DType, ModulatedSqExpKernelType, RationalQuadraticKernelType,
                       Spline12KernelType, Spline32KernelType, Spline34KernelType, StationaryKernelType,
                       TunableRationalQuadraticKernelType)
 from .mixture import (DeviceModel, DeviceQuery, MixtureGPDebugType, MixtureGPType,   # noqa: F401
@@ -19,7 +19,7 @@ from .partition import (BinaryNode, HyperplaneType, PartitionDataType, array2mat
                         convert2itpindex, fetchhyperplanes, findneighbourpartitions, findpartition,
                         getpartitionlines_,
                         organizetrainingsets, setuppartition, tree_from_hyperplanes)
-from .rkhs import (RKHSProblemType, constructkernelmatrix, evalkernel, evalprofile,  # noqa: F401
-                   evalquery, fitRKHS_, query_)
+from .rkhs import (GPQuery, RKHSProblemType, constructkernelmatrix, evalkernel, evalprofile,  # noqa: F401
+                   evalquery, fitRKHS_, query_, setupGPquery)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -81,6 +81,8 @@ SIGNATURES = {
     "pmk_fit_batched": (C.c_int, [_vp, _kp, C.c_double, C.c_int, C.c_int64, _ip, _dpp, _dpp, _vpp, _dpp, _i32p]),
     "pmk_model_load": (C.c_int, [_vp, C.c_int, C.c_int64, _ip, _dpp, _dpp, _dpp, _ip, _vpp]),
     "pmk_model_queryinner": (C.c_int, [_vp, C.c_int64, _kp, C.c_int64, _dp, _dp, _dp]),
+    "pmk_model_queryinner_ex": (C.c_int, [_vp, C.c_int64, _kp, C.c_int64, _dp, C.c_double, _dp, _dp]),
+    "pmk_model_set_weights": (C.c_int, [_vp, _dpp]),
     "pmk_model_set_bsp": (C.c_int, [_vp, _vp, C.c_int64]),
     "pmk_query_create": (C.c_int, [_vp, C.c_int64, _dp, _vpp]),
     "pmk_query_create_items": (C.c_int, [_vp, C.c_int64, C.c_void_p, C.c_void_p, _vpp]),
@@ -104,6 +106,7 @@ SIGNATURES = {
     "pmk_query_destroy": (None, [_vp]),
     "pmk_predict_mixture": (C.c_int, [_vp, _kp, _kp, C.c_int64, _dp, C.c_double, C.c_double, _dp, _dp]),
     "pmk_query_mean": (C.c_int, [_vp, _kp, C.c_int, C.c_int64, _dp, _dp, C.c_int64, _dp, _dp]),
+    "pmk_query_mean_multi": (C.c_int, [_vp, _kp, C.c_int, C.c_int64, _dp, _dp, C.c_int64, _dp, _dp]),
     # include/pmk_test.h
     "pmk_selftest_gemm": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "pmk_selftest_trisolve": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),

@@ -385,7 +385,34 @@ int pmk_query_mean(pmk_ctx *ctx, const pmk_kernel_desc *th, int D, int64_t n, co
     PMK_HIP(hipMemcpyAsync(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, ctx->stream));
     PMK_HIP(hipMemcpyAsync(dc, c, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     PMK_HIP(hipMemcpyAsync(dq, Xq, sizeof(double) * Nq * D, hipMemcpyHostToDevice, ctx->stream));
-    int rc = launch_query_mean(*th, D, n, dx, n, dc, Nq, dq, dy, ctx->stream);
+    int rc = launch_query_mean(th, 1, D, n, dx, n, dc, Nq, dq, dy, ctx->stream);
+    if (!rc) PMK_HIP(hipMemcpyAsync(Yq, dy, sizeof(double) * Nq, hipMemcpyDeviceToHost, ctx->stream));
+    PMK_HIP(hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+int pmk_query_mean_multi(pmk_ctx *ctx, const pmk_kernel_desc *ths, int D, int64_t n, const double *X, const double *c,
+                         int64_t Nq, const double *Xq, double *Yq)
+{
+    if (!ctx) { set_error("pmk_query_mean_multi: ctx is NULL"); return -1; }
+    if (!ths) { set_error("pmk_query_mean_multi: no kernels"); return -2; }
+    if (D < 1 || D > MAX_D) { set_error("pmk_query_mean_multi: D=%d outside 1..%d", D, MAX_D); return -3; }
+    if (n < 1 || !X || !c) { set_error("pmk_query_mean_multi: empty model"); return -4; }
+    for (int64_t i = 0; i < n; ++i)
+        if (!kernel_ok(ths + i)) { set_error("pmk_query_mean_multi: unknown kernel family at centre %lld", (long long)i); return -2; }
+    if (Nq < 1 || !Xq || !Yq) { set_error("pmk_query_mean_multi: empty query (the reference asserts !isempty(Xq))"); return -7; }
+    PMK_HIP(hipSetDevice(ctx->device));
+    std::vector<double> hx((size_t)(n * D));
+    pack_soa(D, n, n, X, hx.data());
+    DevTmp<double> dx, dc, dq, dy;
+    DevTmp<pmk_kernel_desc> dth;
+    if (dx.alloc(n * D) || dc.alloc(n) || dq.alloc(Nq * D) || dy.alloc(Nq) || dth.alloc(n)) return -100;
+    PMK_HIP(hipMemcpyAsync(dx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, ctx->stream));
+    PMK_HIP(hipMemcpyAsync(dc, c, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    PMK_HIP(hipMemcpyAsync(dq, Xq, sizeof(double) * Nq * D, hipMemcpyHostToDevice, ctx->stream));
+    PMK_HIP(hipMemcpyAsync(dth, ths, sizeof(pmk_kernel_desc) * n, hipMemcpyHostToDevice, ctx->stream));
+    int rc = n == 1 ? launch_query_mean(ths, 1, D, n, dx, n, dc, Nq, dq, dy, ctx->stream)
+                    : launch_query_mean(dth, (int)n, D, n, dx, n, dc, Nq, dq, dy, ctx->stream);
     if (!rc) PMK_HIP(hipMemcpyAsync(Yq, dy, sizeof(double) * Nq, hipMemcpyDeviceToHost, ctx->stream));
     PMK_HIP(hipStreamSynchronize(ctx->stream));
     return rc;
@@ -673,8 +700,30 @@ int pmk_model_load(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const doubl
     return 0;
 }
 
+int pmk_model_set_weights(pmk_model *m, const double *const *c)
+{
+    if (!m || !c) { set_error("pmk_model_set_weights: NULL argument"); return -1; }
+    if (!m->fitted) { set_error("pmk_model_set_weights: model is not fitted"); return -3; }
+    PMK_HIP(hipSetDevice(m->ctx->device));
+    PMK_HIP(hipStreamSynchronize(m->ctx->stream));
+    for (int64_t r = 0; r < m->P; ++r) {
+        if (!c[r]) { set_error("pmk_model_set_weights: weights of patch %lld are NULL", (long long)r); return -2; }
+        const PatchDesc &d = m->desc[(size_t)r];
+        std::vector<double> cc((size_t)d.ld, 0.0);
+        std::memcpy(cc.data(), c[r], sizeof(double) * (size_t)d.n);
+        if (int rc = upload_real(m, m->d_c, d.yoff, cc.data(), cc.size())) return rc;
+    }
+    return 0;
+}
+
 int pmk_model_queryinner(pmk_model *m, int64_t patch, const pmk_kernel_desc *th, int64_t Nq, const double *Xq,
                          double *mu, double *var)
+{
+    return pmk_model_queryinner_ex(m, patch, th, Nq, Xq, 1e-12, mu, var);
+}
+
+int pmk_model_queryinner_ex(pmk_model *m, int64_t patch, const pmk_kernel_desc *th, int64_t Nq, const double *Xq,
+                            double min_v, double *mu, double *var)
 {
     if (!m || !m->fitted) { set_error("pmk_model_queryinner: model is not fitted"); return -1; }
     if (patch < 0 || patch >= m->P) { set_error("pmk_model_queryinner: patch %lld of %lld", (long long)patch, (long long)m->P); return -2; }
@@ -684,7 +733,7 @@ int pmk_model_queryinner(pmk_model *m, int64_t patch, const pmk_kernel_desc *th,
     PMK_HIP(hipSetDevice(c->device));
     // a plan by hand: every query is one item of region `patch`, already "sorted"
     pmk_query q;
-    q.m = m; q.Nq = Nq; q.total = Nq;
+    q.m = m; q.Nq = Nq; q.total = Nq; q.min_v = min_v;
     int rc = 0;
     rc |= dev_alloc(&q.d_xq, Nq * m->D);
     rc |= dev_alloc(&q.d_sorted_item, Nq);

@@ -138,6 +138,7 @@ struct pmk_query {
     void *d_tasks = nullptr; int64_t ntasks = 0, tasks_cap = 0, strip_grid = 0;
     uint32_t *d_sync = nullptr; int64_t sync_cap = 0, nsync = 0, round_base = 0;   // arrival counters of the strips' lock-step groups   // prediction strip tasks (owned regions)
     bool planned = false;
+    double min_v = 1e-12;           // floor of the predictive variance (queryinner!'s keyword min_v, mixtureGP.jl:296)
 };
 
 namespace pmk {
@@ -174,7 +175,7 @@ int launch_export_requests(pmk_query *q, int64_t first, int64_t n, double *x_out
 int launch_export_results(pmk_query *q, double *u_out, double *v_out, hipStream_t s);
 int grow_item_buffers(pmk_query *q, int64_t total);
 int launch_explicit_items(pmk_query *q, int *d_bad, hipStream_t s);
-int launch_query_mean(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx,
+int launch_query_mean(const pmk_kernel_desc *th, int nth, int D, int64_t n, const double *d_xs, int64_t ldx,
                       const double *d_c, int64_t nq, const double *d_xq, double *d_yq, hipStream_t s);
 int64_t exclusive_scan_i32_to_i64(const int32_t *d_in, int64_t *d_out, int64_t n, void **tmp, size_t *tmp_bytes,
                                   hipStream_t s);

@@ -50,10 +50,12 @@ int launch_kernel_matrix_dense(const pmk_kernel_desc &th, int D, int64_t n, cons
     return 0;
 }
 
-// query! of the single-problem path (src/RKHS/RKHS.jl:220-247): Yq[j] = sum_i k(xq_j, x_i) c_i
-template <int D>
-__global__ __launch_bounds__(64) void query_mean_kernel(pmk_kernel_desc th, int64_t n, const double *__restrict__ xs,
-                                                        int64_t ldx, const double *__restrict__ c, int64_t nq,
+// query! of the single-problem path (src/RKHS/RKHS.jl:220-247): Yq[j] = sum_i k(xq_j, x_i) c_i; with MULTI the kernel
+// of centre i is ths[i] (the method for RKHSProblemType{Vector{KT}}, RKHS.jl:278-305)
+template <int D, bool MULTI>
+__global__ __launch_bounds__(64) void query_mean_kernel(pmk_kernel_desc th, const pmk_kernel_desc *__restrict__ ths, int64_t n,
+                                                        const double *__restrict__ xs, int64_t ldx,
+                                                        const double *__restrict__ c, int64_t nq,
                                                         const double *__restrict__ xq, double *__restrict__ yq)
 {
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -66,17 +68,23 @@ __global__ __launch_bounds__(64) void query_mean_kernel(pmk_kernel_desc th, int6
         double xi[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) xi[d] = xs[d * ldx + i];
-        s += kern_eval<D>(th, q, xi) * c[i];
+        s += kern_eval<D>(MULTI ? ths[i] : th, q, xi) * c[i];
     }
     yq[j] = s;
 }
 
-int launch_query_mean(const pmk_kernel_desc &th, int D, int64_t n, const double *d_xs, int64_t ldx, const double *d_c,
+// th: ONE kernel (host pointer, nth == 1) or n kernels, one per centre (DEVICE pointer, nth == n)
+int launch_query_mean(const pmk_kernel_desc *th, int nth, int D, int64_t n, const double *d_xs, int64_t ldx, const double *d_c,
                       int64_t nq, const double *d_xq, double *d_yq, hipStream_t s)
 {
     dim3 grid((unsigned)((nq + 63) / 64));
-    PMK_DISPATCH_D(D, hipLaunchKernelGGL(query_mean_kernel<DD>, grid, dim3(64), 0, s, th, n, d_xs, ldx, d_c, nq, d_xq,
-                                         d_yq));
+    if (nth == 1) {
+        PMK_DISPATCH_D(D, hipLaunchKernelGGL((query_mean_kernel<DD, false>), grid, dim3(64), 0, s, *th, nullptr, n, d_xs, ldx,
+                                             d_c, nq, d_xq, d_yq));
+    } else {
+        PMK_DISPATCH_D(D, hipLaunchKernelGGL((query_mean_kernel<DD, true>), grid, dim3(64), 0, s, pmk_kernel_desc{}, th, n, d_xs,
+                                             ldx, d_c, nq, d_xq, d_yq));
+    }
     PMK_HIP(hipGetLastError());
     return 0;
 }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
                                                                const int32_t *__restrict__ item_query,
                                                                const double *__restrict__ xq, real *__restrict__ strips,
                                                                int64_t strip_stride, pmk_kernel_desc th,
-                                                               uint32_t *__restrict__ sync_cnt, int round_base,
+                                                               uint32_t *__restrict__ sync_cnt, int round_base, double min_v,
                                                                double *__restrict__ u_out, double *__restrict__ v_out)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
             if ((lane >> 4) == 0 && valid[ej]) {
                 const real kself = kern_eval<D, FAM, real>(th, q[ej], q[ej]);
                 double var = (double)kself - (double)b;               // mixtureGP.jl:312
-                var = var < 1e-12 ? 1e-12 : var;
+                var = var < min_v ? min_v : var;                     // clamp(..., min_v, Inf)
                 u_out[pos[ej]] = (double)a;
                 v_out[pos[ej]] = var;
             }
@@ -385,11 +385,11 @@ int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s)
         if (s34)                                                                                                       \
             hipLaunchKernelGGL((predict_strip_kernel<DD, PMK_SPLINE34>), dim3((unsigned)q->strip_grid), dim3(PRED_THREADS), 0, s, \
                                m->d_desc, (real *)m->d_x, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
-                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->d_u, q->d_v);  \
+                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->min_v, q->d_u, q->d_v);  \
         else                                                                                                           \
             hipLaunchKernelGGL((predict_strip_kernel<DD, 0>), dim3((unsigned)q->strip_grid), dim3(PRED_THREADS), 0, s,  \
                                m->d_desc, (real *)m->d_x, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
-                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->d_u, q->d_v);  \
+                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->min_v, q->d_u, q->d_v);  \
         break;
         PMK_CASE(1) PMK_CASE(2) PMK_CASE(3) PMK_CASE(4)
 #undef PMK_CASE

@@ -100,6 +100,88 @@ class BrownianBridgeSemiInfDomain(_KernelType):        # declarations.jl:103-105
         self.nparams = theta_base.nparams
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Closure-carrying ("adaptive") kernels: src/misc/declarations.jl:113-130, src/RKHS/kernel.jl:31-59,87-152.
+# A Julia (here: Python) closure cannot cross the C ABI, and it does not have to: each of these kernels is a
+# stationary canonical kernel evaluated on tau^2 = |p - q|^2 + sum_i (g_i(p) - g_i(q))^2 with g_i = a weighted warp
+# function.  The host evaluates the warp functions ONCE per point (the reference's FastAdaptiveKernelType keeps
+# exactly that table as w_X) and appends g_i(x) to the coordinates; the device then runs the canonical kernel on the
+# augmented points (D + #warps <= 4).  Rounding differs from the reference's operation order in the last place when
+# there are two or more warps (it sums the coordinate and the warp squares separately).
+# ---------------------------------------------------------------------------------------------------------------
+class _WarpedKernel:
+    stationary = False
+    warped = True
+
+    def features(self, X):
+        """(N, M) array of the weighted warp values g_i(x_n) appended to the coordinates"""
+        raise NotImplementedError
+
+    def augment(self, X):
+        X = as_points(X)
+        F = np.ascontiguousarray(self.features(X), dtype=np.float64).reshape(X.shape[0], -1)
+        if X.shape[1] + F.shape[1] > 4:
+            raise ValueError("input dimension + number of warp functions must be <= 4 on the device path")
+        return np.ascontiguousarray(np.concatenate([X, F], axis=1))
+
+    @property
+    def canonical(self):
+        raise NotImplementedError
+
+    def desc(self):
+        return self.canonical.desc()
+
+
+class AdaptiveKernelType(_WarpedKernel):               # declarations.jl:118-121, kernel.jl:31-50: one scalar warp
+    def __init__(self, canonical_params, warpfunc):
+        if not getattr(canonical_params, "stationary", False):
+            raise TypeError("the canonical kernel must be stationary")
+        self.canonical_params, self.warpfunc = canonical_params, warpfunc
+
+    canonical = property(lambda self: self.canonical_params)
+
+    def features(self, X):
+        return np.array([[float(self.warpfunc(x))] for x in X])
+
+
+class FastAdaptiveKernelType(_WarpedKernel):           # declarations.jl:123-128, kernel.jl:52-67
+    def __init__(self, canonical_kernel, warpfuncs, w_X, s):
+        if not getattr(canonical_kernel, "stationary", False):
+            raise TypeError("the canonical kernel must be stationary")
+        self.canonical_kernel, self.warpfuncs = canonical_kernel, list(warpfuncs)
+        self.w_X = w_X                                  # pre-computed warp map evaluations at the training positions
+        self.s = np.asarray(s, dtype=np.float64)
+        if len(self.s) != len(self.warpfuncs):
+            raise ValueError("one weight per warp function")
+
+    canonical = property(lambda self: self.canonical_kernel)
+
+    def features(self, X):
+        return np.array([[self.s[i] * float(w(x)) for i, w in enumerate(self.warpfuncs)] for x in X])
+
+    def update_w_X(self, X):
+        """constructkernelmatrix! refreshes θ.w_X from the training positions (RKHS.jl:141-146)"""
+        X = as_points(X)
+        self.w_X = np.array([[float(w(x)) for w in self.warpfuncs] for x in X])
+        return self.w_X
+
+
+class AdaptiveKernelMultiWarpType(_WarpedKernel):      # declarations.jl:130-135, kernel.jl:87-96,119-139
+    def __init__(self, canonical_params, warpfuncs, a):
+        if not getattr(canonical_params, "stationary", False):
+            raise TypeError("the canonical kernel must be stationary")
+        self.canonical_params, self.warpfuncs = canonical_params, list(warpfuncs)
+        self.a = np.asarray(a, dtype=np.float64)
+        if np.any(self.a < 0):
+            raise ValueError("warp weights must be non-negative")
+
+    canonical = property(lambda self: self.canonical_params)
+
+    def features(self, X):
+        r = np.sqrt(self.a)
+        return np.array([[r[m] * float(w(x)) for m, w in enumerate(self.warpfuncs)] for x in X])
+
+
 def as_points(X):
     """Vector{Vector{T}} -> (N, D) C-contiguous float64 (= the D x N packing of array2matrix)"""
     X = np.ascontiguousarray(X, dtype=np.float64)

@@ -838,6 +838,106 @@ def test_split_path_matches_batched_path_and_lapack(P, n, D):
     assert np.array_equal(auto.get(0, M.GET_C), out[1][0][1])
 
 
+# ------------------------------------------------------------------------------------ SURVEY 8(f) ranks 3 and 4, row 17 remainder
+def test_gp_query_with_variance_vs_reference_formula():
+    """setupGPquery / evalqueryGP! (src/RKHS/querying.jl:43-79): mean = c . k, variance = k(x,x) - k' (A \\ k) with
+    A = K + sigma2 I and the CALLER's c, unclamped.  The reference solves A \\ k by LU per query; checked here against
+    exactly that (numpy LU on the oracle's kernel matrix)."""
+    rng = np.random.Generator(np.random.PCG64(41))
+    n, sigma2 = 700, 1e-3
+    X = rng.uniform(-2, 2, (n, 2))
+    c = rng.normal(size=n)                                   # any weights: setupGPquery takes them from its caller
+    th, oth = pmk.Spline34KernelType(0.5), O.kernel(O.SPLINE34, 0.5)
+    fq = pmk.setupGPquery(c, X, th, sigma2)
+    Xq = np.concatenate([rng.uniform(-2, 2, (300, 2)), X[:5]])
+    mu, var = fq.many(Xq)
+    A = O.kernel_matrix(oth, X) + sigma2 * np.eye(n)
+    Kq = O.cross_kernel_matrix(oth, X, Xq)                   # n x nq
+    mu_ref = Kq.T @ c
+    var_ref = np.array([O.kernel_eval(oth, x, x) for x in Xq]) - np.einsum("ij,ij->j", Kq, np.linalg.solve(A, Kq))
+    assert np.abs(mu - mu_ref).max() <= 1e-11 * max(1, np.abs(mu_ref).max())
+    assert np.abs(var - var_ref).max() <= 1e-9                # cancellation 1 - |L^-1 k|^2 at cond(A) ~ 1e5
+    m1, v1 = fq(Xq[7])                                        # the closure form: one point
+    assert (m1, v1) == (mu[7], var[7])
+    assert var[-5:].max() < 2 * sigma2 and var.min() > -1e-9  # at training points the variance is ~ sigma2, never clamped up
+
+
+def test_query_with_one_kernel_per_centre():
+    """query!(Yq, Xq, eta::RKHSProblemType{Vector{KT}}) (RKHS.jl:278-305): kq[i] = evalkernel(Xq[iq], X[i], theta[i])"""
+    rng = np.random.Generator(np.random.PCG64(43))
+    n = 257
+    X = rng.uniform(-1, 1, (n, 3))
+    c = rng.normal(size=n)
+    a_i = rng.uniform(0.3, 1.5, n)
+    fams = [pmk.Spline34KernelType, pmk.Spline12KernelType, pmk.Spline32KernelType]
+    ofam = [O.SPLINE34, O.SPLINE12, O.SPLINE32]
+    ths = [fams[i % 3](a_i[i]) for i in range(n)]
+    oths = [O.kernel(ofam[i % 3], a_i[i]) for i in range(n)]
+    Xq = rng.uniform(-1, 1, (130, 3))
+    eta = pmk.RKHSProblemType(c, X, ths, 0.0)
+    Yq = np.empty(len(Xq))
+    pmk.query_(Yq, Xq, eta)
+    ref = np.array([sum(c[i] * O.kernel_eval(oths[i], xq, X[i]) for i in range(n)) for xq in Xq])
+    assert np.abs(Yq - ref).max() <= 1e-12 * max(1, np.abs(ref).max())
+    with pytest.raises(ValueError):
+        pmk.query_(Yq, Xq, pmk.RKHSProblemType(c, X, ths[:-1], 0.0))
+
+
+def test_closure_carrying_kernels_through_warp_features():
+    """AdaptiveKernelType / FastAdaptiveKernelType / AdaptiveKernelMultiWarpType (kernel.jl:31-67,87-139, RKHS.jl:132-167):
+    the warp closures are evaluated on the host once per point and ride along as extra coordinates of a canonical
+    stationary kernel.  Kernel matrices against the reference's formulas written out in numpy, then fit + query."""
+    rng = np.random.Generator(np.random.PCG64(47))
+    n = 300
+    X = rng.uniform(-1, 1, (n, 2))
+    canon, ocanon = pmk.Spline34KernelType(0.4), O.kernel(O.SPLINE34, 0.4)
+    w1 = lambda x: np.sin(2 * x[0]) * x[1]            # noqa: E731
+    w2 = lambda x: 0.5 * np.cos(x[0] + x[1])           # noqa: E731
+
+    def ref_matrix(tau):
+        K = np.empty((n, n))
+        for i in range(n):
+            for j in range(n):
+                K[i, j] = O.profile(ocanon, tau(X[max(i, j)], X[min(i, j)]))
+        return K
+
+    # one scalar warp (kernel.jl:31-50)
+    th1 = pmk.AdaptiveKernelType(canon, w1)
+    K1 = pmk.constructkernelmatrix(X, th1)
+    R1 = ref_matrix(lambda p, q: np.sqrt(sum((p[d] - q[d]) ** 2 for d in range(2)) + (w1(p) - w1(q)) ** 2))
+    assert np.array_equal(K1, K1.T) and np.abs(K1 - R1).max() <= 1e-14
+    # weighted warps with the pre-computed table (kernel.jl:52-67)
+    s = np.array([0.7, 1.3])
+    th2 = pmk.FastAdaptiveKernelType(canon, [w1, w2], None, s)
+    K2 = pmk.constructkernelmatrix(X, th2)
+    assert th2.w_X.shape == (n, 2) and th2.w_X[5, 1] == w2(X[5])          # constructkernelmatrix! refreshes w_X
+    R2 = ref_matrix(lambda p, q: np.sqrt(sum((p[d] - q[d]) ** 2 for d in range(2))
+                                         + sum((s[i] * (w(p) - w(q))) ** 2 for i, w in enumerate([w1, w2]))))
+    assert np.abs(K2 - R2).max() <= 1e-14 and np.all(np.diag(K2) == 1.0)
+    # multi-warp with weights on the squares (kernel.jl:87-96,119-139)
+    a = np.array([0.5, 2.0])
+    th3 = pmk.AdaptiveKernelMultiWarpType(canon, [w1, w2], a)
+    K3 = pmk.constructkernelmatrix(X, th3)
+    R3 = ref_matrix(lambda p, q: np.sqrt(np.dot(p - q, p - q) + sum(a[m] * (w(p) - w(q)) ** 2 for m, w in enumerate([w1, w2]))))
+    assert np.abs(K3 - R3).max() <= 1e-14
+    assert pmk.evalkernel(X[3], X[9], th2) == K2[9, 3]
+    # fitRKHS! / query! with an adaptive kernel: the fit solves (K + sigma2 I) c = y, the query uses the same warps
+    y = np.sin(3 * X[:, 0]) + X[:, 1]
+    eta = pmk.RKHSProblemType(np.zeros(n), X, th2, 1e-6)
+    pmk.fitRKHS_(eta, y)
+    U = R2 + 1e-6 * np.eye(n)
+    assert np.linalg.norm(U @ eta.c - y) / (np.linalg.norm(U) * np.linalg.norm(eta.c) + np.linalg.norm(y)) <= 1e-12
+    Xq = rng.uniform(-1, 1, (50, 2))
+    Yq = np.empty(50)
+    pmk.query_(Yq, Xq, eta)
+    kq = np.array([[O.profile(ocanon, np.sqrt(sum((xq[d] - x[d]) ** 2 for d in range(2))
+                                              + sum((s[i] * (w(xq) - w(x))) ** 2 for i, w in enumerate([w1, w2]))))
+                    for x in X] for xq in Xq])
+    assert np.abs(Yq - kq @ eta.c).max() <= 1e-9 * max(1, np.abs(kq @ eta.c).max())
+    with pytest.raises(ValueError):                     # 3-D points + 2 warps = 5 coordinates: beyond the device path
+        pmk.constructkernelmatrix(rng.uniform(0, 1, (10, 3)), pmk.FastAdaptiveKernelType(canon, [w1, w2], None, s))
+
+
 def test_config_A_ibb1d_n512():
     """BASELINE config A: IBB1D.jl scaled to N = 512, single patch, BrownianBridge10, sigma2 = 1e-5
     (examples/IBB1D.jl:19-62) -- GPU path against the oracle's fitRKHS! / query!."""
