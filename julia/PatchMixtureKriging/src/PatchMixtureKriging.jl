@@ -82,6 +82,36 @@ function desc(θ::BrownianBridgeSemiInfDomain)
     return KernelDesc(d.family, Int32(1), d.p)
 end
 
+# ------------------------------------------------------------------------------------------ closure-carrying kernels
+# src/misc/declarations.jl:113-135, src/RKHS/kernel.jl:31-67,87-139.  A closure cannot cross the C ABI and need not: every
+# one of these kernels is a stationary canonical kernel on τ² = |p - q|² + Σᵢ (gᵢ(p) - gᵢ(q))² with gᵢ a weighted warp
+# function.  The warp functions are evaluated HERE, once per point (the table the reference's FastAdaptiveKernelType
+# keeps as w_X), and appended to the coordinates; the device evaluates the canonical kernel on the augmented points
+# (input dimension + number of warps ≤ 4).
+struct AdaptiveKernelType{KT}
+    canonical_params::KT
+    warpfunc::Function
+end
+struct FastAdaptiveKernelType{KT,T,D}
+    canonical_kernel::KT
+    warpfuncs::Vector{Function}
+    w_X::Array{T,D}      # pre-computed warp map evaluations at the training positions (refreshed by constructkernelmatrix)
+    s::Vector{T}
+end
+struct AdaptiveKernelMultiWarpType{KT,T}
+    canonical_params::KT
+    warpfuncs::Vector{Function}
+    a::Vector{T}
+end
+const WarpedKernel = Union{AdaptiveKernelType,FastAdaptiveKernelType,AdaptiveKernelMultiWarpType}
+canonical(θ::AdaptiveKernelType) = θ.canonical_params
+canonical(θ::FastAdaptiveKernelType) = θ.canonical_kernel
+canonical(θ::AdaptiveKernelMultiWarpType) = θ.canonical_params
+desc(θ::WarpedKernel) = desc(canonical(θ))
+features(θ::AdaptiveKernelType, x) = [Float64(θ.warpfunc(x))]
+features(θ::FastAdaptiveKernelType, x) = [Float64(θ.s[i] * θ.warpfuncs[i](x)) for i = 1:length(θ.warpfuncs)]
+features(θ::AdaptiveKernelMultiWarpType, x) = [Float64(sqrt(θ.a[m]) * θ.warpfuncs[m](x)) for m = 1:length(θ.warpfuncs)]
+
 # ------------------------------------------------------------------------------------------ helpers
 """array2matrix (src/misc/utilities.jl:25-36): Vector{Vector{T}} -> D x N matrix"""
 function array2matrix(X::Vector{Vector{T}})::Matrix{T} where T
@@ -94,6 +124,13 @@ function array2matrix(X::Vector{Vector{T}})::Matrix{T} where T
 end
 pack(X::Vector{Vector{T}}) where T = Matrix{Float64}(array2matrix(X))
 pack(X::Vector{T}) where T <: Real = reshape(Vector{Float64}(X), 1, length(X))
+# the points the device evaluates kernel θ on: X itself, or X with the warp features appended
+kpack(θ, X) = pack(X)
+function kpack(θ::WarpedKernel, X::Vector{Vector{T}}) where T
+    Xa = [vcat(Vector{Float64}(x), features(θ, x)) for x in X]
+    length(Xa[1]) <= 4 || throw(PMKError("input dimension + number of warp functions must be <= 4 on the device path"))
+    return pack(Xa)
+end
 
 """convert2itpindex (src/misc/utilities.jl:562-579)"""
 function convert2itpindex(x::Vector{T}, a::Vector{T}, b::Vector{T}, M::Vector{Int})::Vector{T} where T <: Real
@@ -104,7 +141,12 @@ end
 # ------------------------------------------------------------------------------------------ kernel matrix
 """constructkernelmatrix(X, θ)::Matrix{Float64} (src/RKHS/RKHS.jl:4-34); host matrix, exactly symmetric"""
 function constructkernelmatrix(X, θ)::Matrix{Float64}
-    Xm = pack(X); D, n = size(Xm)
+    if θ isa FastAdaptiveKernelType                     # RKHS.jl:141-146: refresh the warp table
+        for i = 1:length(θ.warpfuncs), n = 1:length(X)
+            θ.w_X[n, i] = θ.warpfuncs[i](X[n])
+        end
+    end
+    Xm = kpack(θ, X); D, n = size(Xm)
     K = Matrix{Float64}(undef, n, n)
     d = Ref(desc(θ))
     check(ccall((:pmk_kernel_matrix, libpmk), Cint,
@@ -114,7 +156,7 @@ function constructkernelmatrix(X, θ)::Matrix{Float64}
 end
 """constructkernelmatrix(X, Z, θ) (src/RKHS/RKHS.jl:95-110)"""
 function constructkernelmatrix(X::Vector{Vector{T}}, Z::Vector{Vector{T}}, θ)::Matrix{T} where T
-    Xm = pack(X); Zm = pack(Z); D, n = size(Xm); m = size(Zm, 2)
+    Xm = kpack(θ, X); Zm = kpack(θ, Z); D, n = size(Xm); m = size(Zm, 2)
     K = Matrix{Float64}(undef, n, m)
     d = Ref(desc(θ))
     check(ccall((:pmk_kernel_matrix, libpmk), Cint,
@@ -478,7 +520,7 @@ function fitRKHS!(η, y::Vector{T}) where T
     @assert !isempty(η.X)
     @assert !isempty(y)
     @assert length(η.X) == length(y)
-    Xm = pack(η.X); yy = Vector{Float64}(y); D, n = size(Xm)
+    Xm = kpack(η.θ, η.X); yy = Vector{Float64}(y); D, n = size(Xm)
     h = Ref{Ptr{Cvoid}}(C_NULL); info = Vector{Int32}(undef, 1); c = Vector{Float64}(undef, n); d = Ref(desc(η.θ))
     GC.@preserve Xm yy c begin
         rc = ccall((:pmk_fit_batched, libpmk), Cint,
@@ -497,13 +539,58 @@ end
 function query!(Yq::Vector{T}, Xq, η::RKHSProblemType) where T
     @assert !isempty(Xq)
     @assert size(Yq) == size(Xq)
-    Xm = pack(η.X); Qm = pack(Xq); D, n = size(Xm); Nq = size(Qm, 2)
+    Xm = kpack(η.θ, η.X); Qm = kpack(η.θ, Xq); D, n = size(Xm); Nq = size(Qm, 2)
     out = Vector{Float64}(undef, Nq)
     check(ccall((:pmk_query_mean, libpmk), Cint,
         (Ptr{Cvoid}, Ref{KernelDesc}, Cint, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}),
         context(), Ref(desc(η.θ)), D, n, Xm, Vector{Float64}(η.c), Nq, Qm, out), "query!")
     Yq[:] = out
     return nothing
+end
+
+"""query!(Yq, Xq, η::RKHSProblemType{Vector{KT}}) (src/RKHS/RKHS.jl:278-305): one kernel per centre"""
+function query!(Yq::Vector{T}, Xq::Vector{Vector{T}}, η::RKHSProblemType{Vector{KT},T}) where {KT,T}
+    @assert !isempty(Xq)
+    @assert size(Yq) == size(Xq)
+    Xm = pack(η.X); Qm = pack(Xq); D, n = size(Xm); Nq = size(Qm, 2)
+    @assert length(η.θ) == n
+    ds = [desc(θ) for θ in η.θ]
+    out = Vector{Float64}(undef, Nq)
+    check(ccall((:pmk_query_mean_multi, libpmk), Cint,
+        (Ptr{Cvoid}, Ptr{KernelDesc}, Cint, Int64, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}),
+        context(), ds, D, n, Xm, Vector{Float64}(η.c), Nq, Qm, out), "query!")
+    Yq[:] = out
+    return nothing
+end
+
+"""setupGPquery(c, X, θ, σ²) -> fq, fq(xq) = (mean, variance) (src/RKHS/querying.jl:43-79).  The reference's closure
+solves `A \\ k` by LU on every call; here K + σ²I is factorised once on the device and a call is one strip of the
+prediction kernel.  The variance is `k(xq,xq) - k'(A \\ k)` as the reference returns it: not clamped."""
+function setupGPquery(c::Vector{T}, X, θ, σ²::T)::Function where T
+    Xm = kpack(θ, X); D, n = size(Xm)
+    @assert length(c) == n
+    h = Ref{Ptr{Cvoid}}(C_NULL); info = Vector{Int32}(undef, 1); y0 = zeros(Float64, n); d = Ref(desc(θ))
+    GC.@preserve Xm y0 begin
+        rc = ccall((:pmk_fit_batched, libpmk), Cint,
+            (Ptr{Cvoid}, Ref{KernelDesc}, Float64, Cint, Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}},
+             Ref{Ptr{Cvoid}}, Ptr{Ptr{Float64}}, Ptr{Int32}),
+            context(), d, σ², D, 1, Int64[n], [pointer(Xm)], [pointer(y0)], h, C_NULL, info)
+    end
+    check(rc, "setupGPquery")
+    info[1] == 0 || throw(PosDefException(Int(info[1])))
+    cc = Vector{Float64}(c)
+    GC.@preserve cc check(ccall((:pmk_model_set_weights, libpmk), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}), h[], [pointer(cc)]),
+                          "pmk_model_set_weights")
+    model = Ref(h[])
+    finalizer(m -> (ccall((:pmk_model_destroy, libpmk), Cvoid, (Ptr{Cvoid},), m[]); nothing), model)
+    return xx -> evalqueryGP!(model, xx, θ)
+end
+function evalqueryGP!(model::Ref{Ptr{Cvoid}}, xq::Vector{T}, θ)::Tuple{T,T} where T
+    Qm = kpack(θ, [xq]); μ = Ref(0.0); v = Ref(0.0)
+    check(ccall((:pmk_model_queryinner_ex, libpmk), Cint,
+        (Ptr{Cvoid}, Int64, Ref{KernelDesc}, Int64, Ptr{Float64}, Float64, Ref{Float64}, Ref{Float64}),
+        model[], 0, Ref(desc(θ)), 1, Qm, -Inf, μ, v), "evalqueryGP!")
+    return μ[], v[]
 end
 
 """evalquery(x, c, X, θ) (src/RKHS/querying.jl:2-5)"""
