@@ -506,8 +506,10 @@ int pmk_model_create_ex(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const 
                          [&](int32_t a2, int32_t b2) { return m->desc[(size_t)a2].nt > m->desc[(size_t)b2].nt; });
         // one workgroup per block row fills the chip only if there are enough patches: P (max_nt - 1) / 2 block rows per
         // step on average against two workgroups per CU.  Below that -- single large problems, fitRKHS! at scale -- the
-        // factorisation takes the split path (pmk_chol.hip).
-        m->split_mode = m->max_nt >= 8 && P * (int64_t)(m->max_nt - 1) / 2 < 2 * (int64_t)ctx->num_cu;
+        // factorisation takes the split path (pmk_chol.hip).  The two paths sum in different orders (last-bit differences
+        // in L), so the choice is kept away from everyday batches: only patches of >= 32 tiles (n > 3968) qualify, and a
+        // model and its shards -- which hold the same patch sizes -- then decide alike unless they straddle P's bound.
+        m->split_mode = m->max_nt >= 32 && P * (int64_t)(m->max_nt - 1) / 2 < 2 * (int64_t)ctx->num_cu;
         m->active_prefix.assign((size_t)m->max_nt + 2, 0);
         for (int64_t r = 0; r < P; ++r)
             for (int t = 0; t <= m->desc[(size_t)r].nt; ++t) ++m->active_prefix[(size_t)t];

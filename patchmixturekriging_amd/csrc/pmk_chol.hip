@@ -740,13 +740,12 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
             }
             PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].first, s));
         }
-        // split path: K chunks so that tiles x chunks fills the chip; a chunk is at least two block columns deep
+        // split path: K chunks so that ONE patch's tiles x chunks would fill the chip (a function of the step alone, not
+        // of the number of patches: the summation order of a tile, hence every bit of the factor, is then the same
+        // whether a patch is factorised alone or next to others -- sharded and single models stay bit-identical); a
+        // chunk is at least two block columns deep; 64-way: the serial sum in the combine costs more than it buys
         int nsplit = 1;
-        if (m->split_mode && l >= 4) {
-            const int tiles = nactive * (G + 1);
-            nsplit = std::min(std::min(16, l / 2), (want_wg + tiles - 1) / tiles);   // 64-way: the serial sum in the combine costs more than it buys
-            nsplit = std::max(nsplit, 1);
-        }
+        if (m->split_mode && l >= 4) nsplit = std::max(1, std::min(std::min(16, l / 2), (want_wg + G) / (G + 1)));
         const unsigned grid = (unsigned)(8 * ((nactive + 7) / 8) * G);
         if (nsplit > 1) {
             const int tiles = G + 1;
@@ -777,7 +776,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
 static int launch_split_solves(pmk_model *m, hipStream_t s)
 {
     const int P = (int)m->P;
-    const int max_chunks = std::max(1, std::min(256, 2 * m->ctx->num_cu / P));
+    const int max_chunks = 128;      // a function of the block alone, not of P: bit-identical results however patches are grouped
     if (int rc = reserve_split(m, 0, sizeof(real) * (size_t)P * max_chunks * TILE)) return rc;
     real *part = (real *)m->d_solve_part;
     for (int dir = 0; dir < 2; ++dir) {
