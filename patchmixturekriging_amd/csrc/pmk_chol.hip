@@ -198,147 +198,107 @@ __global__ __launch_bounds__(256, 2) void chol_first_kernel(const PatchDesc *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// one block column of every active patch.  Workgroup = one 128-row block row = 4 waves x (32 rows x 128 columns);
-// in the GEMM + TRSM part the waves are independent (no barrier after the operand staging) and two workgroups
-// share a CU (2 waves per SIMD).
+// The two building blocks of a factorisation step, for one workgroup of 256 threads.
 // ---------------------------------------------------------------------------------------------
-// SPLIT > 0 (single large problems, P too small to fill the chip with one workgroup per block row): the deep GEMMs
-// were done by chol_partial_kernel, SPLIT-way split along K, and left as partial tiles; this kernel then adds them up,
-// applies block column k itself (128 deep) and carries on as above -- except that the forward-solve right-hand side is
-// not carried along (z comes from the separate solve sweeps of that path).
+// Block row `row` of block column k of one patch:  T = A[row,k] - L[row,0:k] L[k,0:k]^T  on MFMA (4 waves x (32 rows x
+// 128 columns), the waves independent after the operand staging), then  L[row,k] = T L[kk]^-T  by in-register block
+// substitution.  SPLIT: the deep product arrives as `nsplit` partial tiles instead (chol_partial_kernel).
+// Entered by all threads; contains one barrier (after the staging of the TRSM operands in `lds`); the caller
+// synchronises before `lds` is reused.
 template <int SPLIT>
-__global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__restrict__ descs,
-                                                           const int32_t *__restrict__ order, int nactive, int G,
-                                                           int launch, int max_nt, real *__restrict__ A,
-                                                           real *__restrict__ ninv, const real *__restrict__ y,
-                                                           real *__restrict__ z, int32_t *__restrict__ info,
-                                                           const real2_t *__restrict__ partial, int nsplit)
+__device__ __forceinline__ void block_row_update(const PatchDesc &pd, real *__restrict__ S, const real *__restrict__ ninv_p,
+                                                 int k, int row, real *lds, const real2_t *__restrict__ pt, int nsplit)
 {
-    __shared__ real lds[TRI_LDS_DOUBLES];
-    // (patch slot, block row) from the hardware block id.  Blocks are dealt round-robin over the 8 XCDs (block b runs on
-    // XCD b % 8): XCD x takes the patch slots x, x + 8, x + 16, ... (sizes interleaved, so ragged batches load the XCDs
-    // evenly) and ALL block rows of those patches -- they stream the same block row k of L, which that XCD's L2 then
-    // fetches once.  Within an XCD the critical workgroups (bx == 0) have the lowest ids: they are dispatched first.
-    // The grid is padded to 8 x ceil(nactive / 8) x G; the surplus workgroups of the short XCDs exit here.
-    int slot, bx;
-    if (SPLIT) {
-        // few patches: their block rows are dealt over ALL XCDs (one XCD per patch would leave most of the chip idle);
-        // critical workgroups first
-        const int lid = blockIdx.x;
-        if (lid >= nactive * G) return;
-        if (lid < nactive) { slot = lid; bx = 0; }
-        else { const int j = lid - nactive; slot = j / (G - 1); bx = 1 + j % (G - 1); }
-    } else {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int per = (nactive - xcd + 7) >> 3;             // patch slots of this XCD
-        if (idx >= per * G) return;
-        int loc;
-        if (idx < per) { loc = idx; bx = 0; }
-        else { const int j = idx - per; loc = j / (G - 1); bx = 1 + j % (G - 1); }
-        slot = xcd + 8 * loc;
-    }
-    const int pid = order[slot];
-    const PatchDesc pd = descs[pid];
-    const int k = launch - (max_nt - pd.nt);      // this patch's block column (end-aligned schedule): 0 <= k < nt - 1
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    real *S = A + pd.aoff;
+    // the thread index is made opaque per call: called from inside a loop, the compiler otherwise hoists the 32
+    // lane-dependent tile offsets (and the 64-bit addresses built on them) out of the loop, keeps them live across the
+    // GEMM and spills them
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int64_t ld = pd.ld;
     const int64_t c0 = (int64_t)k * TILE;
-#ifdef PMK_TRACE
-    if (launch == PMK_TRACE && tid == 0 && blockIdx.x < TRACE_MAX_WG) {
-        unsigned xcc, hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        g_trace[TRACE_WORDS * blockIdx.x + 0] = ((unsigned long long)slot << 32) | (unsigned)bx;
-        g_trace[TRACE_WORDS * blockIdx.x + 1] = ((unsigned long long)hwid << 32) | (xcc & 0xf);
-        g_trace[TRACE_WORDS * blockIdx.x + 6] = 0;
-        g_trace[TRACE_WORDS * blockIdx.x + 7] = __builtin_amdgcn_s_memtime();       // shader clock at the start
+    const int64_t r0 = (int64_t)row * TILE + 32 * wave;
+    // a wave whose 32 rows all lie in the identity padding (row index >= n) has nothing to compute: those rows of
+    // L stay zero.  It still takes part in the operand staging and its barrier.  (n = 2000: one wave of the last
+    // block row in every step, 4 % of the MFMA work of a fit.)
+    const bool live = r0 < pd.n;
+    real *out = S + r0 + 2 * (lane & 15) + c0 * ld;   // rows of this lane, first column of the block column
+    // acc starts as -A[rows, block column k]; the GEMM adds L[rows,0:k] L[k,0:k]^T, so acc = -T.  The tile comes
+    // from HBM (first touch): its loads are issued before the operand staging so that the two latencies overlap
+    // instead of adding up.
+    WaveTile<4, 1> acc;   // I = the 128 columns of block column k, J = 32 rows
+    if (live) {
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = tile_i(fi, lane, q);
+                const real2_t a = *reinterpret_cast<const real2_t *>(out + cl * ld);
+                acc.f[fi][0][q] = a[0];
+                acc.f[fi][1][q] = a[1];
+            }
     }
-#endif
-    PMK_STAMP(2);
-
-    // ---- block row k + 1 + bx of block column k
-    {
-        const int64_t r0 = (int64_t)(k + 1 + bx) * TILE + 32 * wave;
-        // a wave whose 32 rows all lie in the identity padding (row index >= n) has nothing to compute: those rows of
-        // L stay zero.  It still takes part in the operand staging and its barrier.  (n = 2000: one wave of the last
-        // block row in every step, 4 % of the MFMA work of a fit.)
-        const bool live = r0 < pd.n;
-        real *out = S + r0 + 2 * (lane & 15) + c0 * ld;   // rows of this lane, first column of the block column
-        // acc starts as -A[rows, block column k]; the GEMM adds L[rows,0:k] L[k,0:k]^T, so acc = -T.  The tile comes
-        // from HBM (first touch): its loads are issued before the operand staging so that the two latencies overlap
-        // instead of adding up.
-        WaveTile<4, 1> acc;   // I = the 128 columns of block column k, J = 32 rows
-        if (live) {
-#pragma unroll
-            for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int cl = tile_i(fi, lane, q);
-                    const real2_t a = *reinterpret_cast<const real2_t *>(out + cl * ld);
-                    acc.f[fi][0][q] = a[0];
-                    acc.f[fi][1][q] = a[1];
-                }
-        }
-        __builtin_amdgcn_sched_barrier(0);      // keep the tile loads ahead of the staging loads
-        // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per workgroup
-        stage_tri_operands(lds, S + c0 + c0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, 256);
-        __syncthreads();
-        if (live) {
-#pragma unroll
-            for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc.f[fi][0][q] = -acc.f[fi][0][q];
-                    acc.f[fi][1][q] = -acc.f[fi][1][q];
-                }
-            if (SPLIT) {
-                // tile bx of this patch's G + 1 tiles: the partial products L[rows, Kc] L[k, Kc]^T of the K chunks
-                const real2_t *pt = partial + (((int64_t)slot * (G + 1) + bx) * nsplit) * PARTIAL_TILE + wave * (PARTIAL_TILE / 4) + lane;
-                for (int sp = 0; sp < nsplit; ++sp, pt += PARTIAL_TILE)
-#pragma unroll
-                    for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const real2_t v = pt[(fi * 4 + q) * 64];
-                            acc.f[fi][0][q] += v[0];
-                            acc.f[fi][1][q] += v[1];
-                        }
-            } else if (k > 0) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
-            // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
-            tri_solve_inplace<1>(acc, lds, lane);
-#pragma unroll
-            for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int cl = tile_i(fi, lane, q);
-                    real2_t o;
-                    o[0] = acc.f[fi][0][q];
-                    o[1] = acc.f[fi][1][q];
-                    *reinterpret_cast<real2_t *>(out + cl * ld) = o;
-                }
-        }
-    }
-    PMK_STAMP(3);
-#ifdef PMK_TRACE
-    if (launch == PMK_TRACE && tid == 0 && blockIdx.x < TRACE_MAX_WG)      // shader cycles of wave 0's block-row phase
-        g_trace[TRACE_WORDS * blockIdx.x + 7] = __builtin_amdgcn_s_memtime() - g_trace[TRACE_WORDS * blockIdx.x + 7];
-    if (launch == PMK_TRACE && lane == 0 && blockIdx.x < TRACE_MAX_WG)
-        atomicMax(&g_trace[TRACE_WORDS * blockIdx.x + 6], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
-    if (bx != 0) return;
-
-    // ================= critical workgroup: look-ahead + potrf of diagonal tile k + 1 =================
-    // all four waves have stored their rows of L[k+1, k] (same CU: visible through its L1 after the barrier), and
-    // nobody reads the TRSM operands in LDS any more
+    __builtin_amdgcn_sched_barrier(0);      // keep the tile loads ahead of the staging loads
+    // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per workgroup
+    stage_tri_operands(lds, S + c0 + c0 * ld, ld, ninv_p + (int64_t)k * (4 * SB * SB), tid, 256);
     __syncthreads();
-    const int64_t t0 = c0 + TILE;
+    if (!live) return;
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc.f[fi][0][q] = -acc.f[fi][0][q];
+            acc.f[fi][1][q] = -acc.f[fi][1][q];
+        }
+    if (SPLIT) {
+        pt += wave * (PARTIAL_TILE / 4) + lane;
+        for (int sp = 0; sp < nsplit; ++sp, pt += PARTIAL_TILE)
+#pragma unroll
+            for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const real2_t v = pt[(fi * 4 + q) * 64];
+                    acc.f[fi][0][q] += v[0];
+                    acc.f[fi][1][q] += v[1];
+                }
+    } else if (k > 0) {
+        gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
+    }
+    // L[rows, k]^T = L[kk]^-1 T^T = -L[kk]^-1 (-T)^T : exactly what the block substitution returns
+    tri_solve_inplace<1>(acc, lds, lane);
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cl = tile_i(fi, lane, q);
+            real2_t o;
+            o[0] = acc.f[fi][0][q];
+            o[1] = acc.f[fi][1][q];
+            *reinterpret_cast<real2_t *>(out + cl * ld) = o;
+        }
+}
+
+// The continuation of the workgroup that made block row k + 1 of block column k: look-ahead
+//     A[k+1,k+1] -= L[k+1,0:k+1] L[k+1,0:k+1]^T,    rhs = y_{k+1} - L[k+1,0:k+1] z_{0:k+1},
+// then the potrf of the tile (-> L[k+1,k+1], its -D^-1 blocks, z_{k+1}).  Entered after a barrier that follows the
+// stores of L[k+1, k] (same CU: visible through its L1) and the last use of `lds`.
+template <int SPLIT>
+__device__ __forceinline__ void lookahead_potrf(const PatchDesc &pd, real *__restrict__ S, real *__restrict__ ninv_p,
+                                                const real *__restrict__ y_p, real *__restrict__ z_p,
+                                                int32_t *__restrict__ info_p, int k, real *lds,
+                                                const real2_t *__restrict__ pt, int nsplit)
+{
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                     // see block_row_update
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t ld = pd.ld;
+    const int64_t c0 = (int64_t)k * TILE, t0 = c0 + TILE;
     const int K2 = (k + 1) * TILE;                    // block columns 0..k
     const int h = wave >> 1, g = wave & 1;            // 64-row half, 64-column half of the tile
     real *Att = S + t0 + t0 * ld;
     if (SPLIT) {
-        // the look-ahead tile arrives as partial products too (tile index G, block columns 0..k-1); block column k --
-        // made above -- is applied here.  All four waves, 32 rows x 128 columns each: the part above the diagonal is
+        // the look-ahead tile arrives as partial products too (block columns 0..k-1); block column k -- made just
+        // before -- is applied here.  All four waves, 32 rows x 128 columns each: the part above the diagonal is
         // computed along (never read by anyone: the potrf below takes the lower triangle only).
         WaveTile<4, 1> acc;
         real *outl = Att + 32 * wave + 2 * (lane & 15);
@@ -350,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
                 acc.f[fi][0][q] = -a[0];
                 acc.f[fi][1][q] = -a[1];
             }
-        const real2_t *pt = partial + (((int64_t)slot * (G + 1) + G) * nsplit) * PARTIAL_TILE + wave * (PARTIAL_TILE / 4) + lane;
+        pt += wave * (PARTIAL_TILE / 4) + lane;
         for (int sp = 0; sp < nsplit; ++sp, pt += PARTIAL_TILE)
 #pragma unroll
             for (int fi = 0; fi < 8; ++fi)
@@ -370,10 +330,10 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
                 o[1] = -acc.f[fi][1][q];
                 *reinterpret_cast<real2_t *>(outl + tile_i(fi, lane, q) * ld) = o;
             }
-        if (tid < TILE) lds[POTRF_RHS + tid] = (real)0;
+        if (tid < TILE) lds[POTRF_RHS + tid] = (real)0;       // z comes from the solve sweeps of the split path
     } else if (!(h == 0 && g == 1)) {
-        // A[k+1,k+1] -= L[k+1,0:k+1] L[k+1,0:k+1]^T, lower 64 x 64 sub-tiles: acc = -A up-front (all the sub-tile's
-        // loads in flight at once), the GEMM adds L L^T, the store negates
+        // lower 64 x 64 sub-tiles: acc = -A up-front (all the sub-tile's loads in flight at once), the GEMM adds
+        // L L^T, the store negates
         WaveTile<2, 2> acc;
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
@@ -402,10 +362,8 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
                     *reinterpret_cast<real2_t *>(Att + rl + (int64_t)cl * ld) = a;
                 }
     } else {
-        // the wave without a GEMM sub-tile does the forward-solve right-hand side, two rows per lane:
-        // rhs = y_{k+1} - L[k+1, 0:k+1] z_{0:k+1}
+        // the wave without a GEMM sub-tile does the forward-solve right-hand side, two rows per lane
         const real *Lr = S + t0 + 2 * lane;
-        const real *zz = z + pd.yoff;
         real2_t s0 = {0.0, 0.0}, s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, s3 = {0.0, 0.0};
         for (int c = 0; c < K2; c += 16) {     // 16 independent column loads in flight per batch
             real2_t av[16];
@@ -413,17 +371,96 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
             for (int u = 0; u < 16; ++u) av[u] = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + u) * ld);
 #pragma unroll
             for (int u = 0; u < 16; u += 4) {
-                s0 += av[u] * zz[c + u]; s1 += av[u + 1] * zz[c + u + 1];
-                s2 += av[u + 2] * zz[c + u + 2]; s3 += av[u + 3] * zz[c + u + 3];
+                s0 += av[u] * z_p[c + u]; s1 += av[u + 1] * z_p[c + u + 1];
+                s2 += av[u + 2] * z_p[c + u + 2]; s3 += av[u + 3] * z_p[c + u + 3];
             }
         }
         const real2_t sum = (s0 + s1) + (s2 + s3);
-        const real2_t yy = *reinterpret_cast<const real2_t *>(y + pd.yoff + t0 + 2 * lane);
+        const real2_t yy = *reinterpret_cast<const real2_t *>(y_p + t0 + 2 * lane);
         *reinterpret_cast<real2_t *>(lds + POTRF_RHS + 2 * lane) = yy - sum;
     }
     __syncthreads();
+    tile_potrf(Att, ld, lds, ninv_p + (int64_t)(k + 1) * (4 * SB * SB), z_p + t0, info_p, k + 1);
+}
+
+// (patch slot, block row) of a step-type launch from the hardware block id.  Blocks are dealt round-robin over the 8
+// XCDs (block b runs on XCD b % 8): XCD x takes the patch slots x, x + 8, x + 16, ... (sizes interleaved, so ragged
+// batches load the XCDs evenly) and ALL block rows of those patches -- they stream the same block row k of L, which
+// that XCD's L2 then fetches once.  Within an XCD the critical workgroups (bx == 0) have the lowest ids: they are
+// dispatched first.  The grid is padded to 8 x ceil(nslots / 8) x G; surplus workgroups get slot = -1.
+__device__ __forceinline__ void step_slot(int nslots, int G, int &slot, int &bx)
+{
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int per = (nslots - xcd + 7) >> 3;             // patch slots of this XCD
+    slot = -1; bx = 0;
+    if (idx >= per * G) return;
+    int loc;
+    if (idx < per) { loc = idx; bx = 0; }
+    else { const int j = idx - per; loc = j / (G - 1); bx = 1 + j % (G - 1); }
+    slot = xcd + 8 * loc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one block column of every active patch.  Workgroup = one 128-row block row; two workgroups share a CU (2 waves per
+// SIMD).  The workgroup of block row k + 1 (bx == 0) is the critical one and continues alone (lookahead_potrf).
+// SPLIT > 0 (single large problems, P too small to fill the chip with one workgroup per block row): the deep GEMMs
+// were done by chol_partial_kernel, SPLIT-way split along K, and left as partial tiles; this kernel then adds them up,
+// applies block column k itself (128 deep) and carries on as above -- except that the forward-solve right-hand side is
+// not carried along (z comes from the separate solve sweeps of that path).
+// ---------------------------------------------------------------------------------------------
+template <int SPLIT>
+__global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__restrict__ descs,
+                                                           const int32_t *__restrict__ order, int nactive, int G,
+                                                           int launch, int max_nt, real *__restrict__ A,
+                                                           real *__restrict__ ninv, const real *__restrict__ y,
+                                                           real *__restrict__ z, int32_t *__restrict__ info,
+                                                           const real2_t *__restrict__ partial, int nsplit)
+{
+    __shared__ real lds[TRI_LDS_DOUBLES];
+    int slot, bx;
+    if (SPLIT) {
+        // few patches: their block rows are dealt over ALL XCDs (one XCD per patch would leave most of the chip idle);
+        // critical workgroups first
+        const int lid = blockIdx.x;
+        if (lid >= nactive * G) return;
+        if (lid < nactive) { slot = lid; bx = 0; }
+        else { const int j = lid - nactive; slot = j / (G - 1); bx = 1 + j % (G - 1); }
+    } else {
+        step_slot(nactive, G, slot, bx);
+        if (slot < 0) return;
+    }
+    const int pid = order[slot];
+    const PatchDesc pd = descs[pid];
+    const int k = launch - (max_nt - pd.nt);      // this patch's block column (end-aligned schedule): 0 <= k < nt - 1
+    real *S = A + pd.aoff;
+#ifdef PMK_TRACE
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (launch == PMK_TRACE && tid == 0 && blockIdx.x < TRACE_MAX_WG) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_trace[TRACE_WORDS * blockIdx.x + 0] = ((unsigned long long)slot << 32) | (unsigned)bx;
+        g_trace[TRACE_WORDS * blockIdx.x + 1] = ((unsigned long long)hwid << 32) | (xcc & 0xf);
+        g_trace[TRACE_WORDS * blockIdx.x + 6] = 0;
+        g_trace[TRACE_WORDS * blockIdx.x + 7] = __builtin_amdgcn_s_memtime();       // shader clock at the start
+    }
+#endif
+    PMK_STAMP(2);
+    block_row_update<SPLIT>(pd, S, ninv + pd.ioff, k, k + 1 + bx, lds,
+                            SPLIT ? partial + (((int64_t)slot * (G + 1) + bx) * nsplit) * PARTIAL_TILE : nullptr, nsplit);
+    PMK_STAMP(3);
+#ifdef PMK_TRACE
+    if (launch == PMK_TRACE && tid == 0 && blockIdx.x < TRACE_MAX_WG)      // shader cycles of wave 0's block-row phase
+        g_trace[TRACE_WORDS * blockIdx.x + 7] = __builtin_amdgcn_s_memtime() - g_trace[TRACE_WORDS * blockIdx.x + 7];
+    if (launch == PMK_TRACE && lane == 0 && blockIdx.x < TRACE_MAX_WG)
+        atomicMax(&g_trace[TRACE_WORDS * blockIdx.x + 6], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+    if (bx != 0) return;
+    // ================= critical workgroup: look-ahead + potrf of diagonal tile k + 1 =================
+    __syncthreads();
     PMK_STAMP(4);
-    tile_potrf(Att, ld, lds, ninv + pd.ioff + (int64_t)(k + 1) * (4 * SB * SB), z + pd.yoff + t0, info + pid, k + 1);
+    lookahead_potrf<SPLIT>(pd, S, ninv + pd.ioff, y + pd.yoff, z + pd.yoff, info + pid, k, lds,
+                           SPLIT ? partial + (((int64_t)slot * (G + 1) + G) * nsplit) * PARTIAL_TILE : nullptr, nsplit);
     PMK_STAMP(5);
 }
 
@@ -723,23 +760,35 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
     PMK_HIP(hipMemsetAsync(m->d_info, 0, sizeof(int32_t) * (size_t)np, s));
     pmk_ctx *c = m->ctx;
     c->panel_n = 0;
-    hipLaunchKernelGGL(chol_first_kernel, dim3((unsigned)np), dim3(256), 0, s, m->d_desc, (real *)m->d_a, (real *)m->d_inv,
-                       (const real *)m->d_y, (real *)m->d_z, m->d_info);
     const bool fine = c->timers >= 2;
     const int want_wg = 2 * c->num_cu;                     // workgroups that fill the chip (two per CU)
-    for (int l = 0; l + 1 < m->max_nt; ++l) {
-        // patches with nt >= max_nt - l are active: a prefix of `order` (sorted by nt, largest first)
-        const int nactive = m->active_prefix[(size_t)(m->max_nt - l)];
-        const int G = m->max_nt - l - 1;                   // block rows below the diagonal, the same for every active patch
-        if (fine) {
-            while ((int)c->panel_ev.size() <= l) {
-                hipEvent_t a, b;
-                PMK_HIP(hipEventCreate(&a));
-                PMK_HIP(hipEventCreate(&b));
-                c->panel_ev.push_back({a, b});
-            }
-            PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].first, s));
+    auto ev_begin = [&](int l) -> int {
+        if (!fine) return 0;
+        while ((int)c->panel_ev.size() <= l) {
+            hipEvent_t a, b;
+            PMK_HIP(hipEventCreate(&a));
+            PMK_HIP(hipEventCreate(&b));
+            c->panel_ev.push_back({a, b});
         }
+        PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].first, s));
+        return 0;
+    };
+    auto ev_end = [&](int l) -> int {
+        if (!fine) return 0;
+        PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].second, s));
+        c->panel_n = l + 1;
+        return 0;
+    };
+    const int l0 = 0;
+    hipLaunchKernelGGL(chol_first_kernel, dim3((unsigned)np), dim3(256), 0, s, m->d_desc, (real *)m->d_a, (real *)m->d_inv,
+                       (const real *)m->d_y, (real *)m->d_z, m->d_info);
+    for (int l = l0; l + 1 < m->max_nt; ++l) {
+        // patch p runs block column k = l - (max_nt - nt_p) at launch l (end-aligned); it takes part from k = l0 on:
+        // nt_p >= max_nt - l + l0.  Those patches are a prefix of `order` (sorted by nt, largest first).
+        const int nactive = m->active_prefix[(size_t)std::min(m->max_nt + 1, m->max_nt - l + l0)];
+        const int G = m->max_nt - l - 1;                   // block rows below the diagonal, the same for every active patch
+        if (nactive == 0) continue;
+        if (int rc = ev_begin(l)) return rc;
         // split path: K chunks so that ONE patch's tiles x chunks would fill the chip (a function of the step alone, not
         // of the number of patches: the summation order of a tile, hence every bit of the factor, is then the same
         // whether a patch is factorised alone or next to others -- sharded and single models stay bit-identical); a
@@ -762,10 +811,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
                                m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,
                                (const real2_t *)nullptr, 1);
         }
-        if (fine) {
-            PMK_HIP(hipEventRecord(c->panel_ev[(size_t)l].second, s));
-            c->panel_n = l + 1;
-        }
+        if (int rc = ev_end(l)) return rc;
     }
     PMK_HIP(hipGetLastError());
     return 0;
