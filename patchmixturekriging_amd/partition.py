@@ -248,7 +248,8 @@ def getpartitionlines_(y_set, t_set, node, level, min_t, max_t, max_N_t, centroi
     m, b = get2Dline(node.data.hp.v, node.data.hp.c)
     t = np.linspace(min_t, max_t, int(max_N_t))
     y = m * t + b
-    near = np.hypot(t - centroid[0], y - centroid[1]) < max_dist
+    dt, dy = t - centroid[0], y - centroid[1]
+    near = np.sqrt(dt * dt + dy * dy) < max_dist          # norm(xx - centroid): sum of squares, then sqrt
     yp, tp = prunepartitionline(node, y[near], t[near])
     y_set.append(yp)
     t_set.append(tp)

@@ -174,3 +174,30 @@ def test_getpartitionlines_host_helper():
     for hp, y, t in zip(hps, y_set, t_set):
         assert np.abs(hp.v[0] * t + hp.v[1] * y - hp.c).max() < 1e-12
     assert len(t_set[0]) > len(t_set[1])                             # children are clipped by the parent plane
+
+    # the reference's routine restated literally with scalar loops (visualize_2D.jl:14-83: LinRange samples, findall by
+    # distance from the centroid, then findall by every ancestor's `dot(v, xx) < c` / its negation): identical arrays
+    def ref_lines(node, level, out):
+        m, b = -node.data.hp.v[0] / node.data.hp.v[1], node.data.hp.c / node.data.hp.v[1]
+        ts = [-2.0 + (2.0 - -2.0) * i / (500 - 1) for i in range(500)]
+        pts = [(t, m * t + b) for t in np.linspace(-2.0, 2.0, 500)]
+        pts = [p for p in pts if np.sqrt((p[0] - centroid[0]) ** 2 + (p[1] - centroid[1]) ** 2) < 3.0]
+        nd = node
+        while nd.parent is not None:
+            v, c = nd.parent.data.hp.v, nd.parent.data.hp.c
+            if nd.parent.right is nd:
+                pts = [p for p in pts if not (v[0] * p[0] + v[1] * p[1] < c)]
+            else:
+                pts = [p for p in pts if v[0] * p[0] + v[1] * p[1] < c]
+            nd = nd.parent
+        out.append(pts)
+        if level != 2:
+            ref_lines(node.left, level - 1, out)
+            ref_lines(node.right, level - 1, out)
+        del ts
+
+    ref = []
+    ref_lines(root, levels, ref)
+    assert len(ref) == len(y_set)
+    for pts, y, t in zip(ref, y_set, t_set):
+        assert np.array_equal(np.array([p[0] for p in pts]), t) and np.array_equal(np.array([p[1] for p in pts]), y)

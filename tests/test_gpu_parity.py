@@ -428,6 +428,64 @@ def test_config_C_full_size_properties():
     assert worst_y <= 1e-7 and worst_v <= 1.0, (worst_y, worst_v)
 
 
+@pytest.mark.timeout(900)
+def test_config_C_ragged_eps_patches_vs_oracle():
+    """Config C's points with the example's ε-overlap (bench.py --eps 0.044): 256 RAGGED patches whose sizes straddle the
+    128-row tile count (16 / 17 / 18 block rows), i.e. the end-aligned schedule of the step kernel with patches that
+    join late.  The smallest, the largest and a median patch against the oracle's factorisation (L element-wise,
+    c by residual and against the oracle's Cholesky weights), all patches through info == 0 and the ε-sets against the
+    oracle's organizetrainingsets, and a sample of mixture predictions against the oracle's queryinner."""
+    N, levels, eps = 512000, 9, 0.044
+    rng = np.random.Generator(np.random.PCG64(25))
+    X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+    y = oracle_f(X)
+    th, wth = pmk.Spline34KernelType(1 / 15), pmk.Spline34KernelType(1 / 0.088)
+    oth = O.kernel(O.SPLINE34, 1 / 15)
+    root, X_parts, _ = pmk.setuppartition(X, levels)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, X, eps)
+    sizes = np.array([len(x) for x in X_set])
+    assert sizes.min() >= 2000 and len(set((sizes + 127) // 128)) >= 2, (sizes.min(), sizes.max())
+    ob = O.BSP(X, levels)
+    o_off, o_inds, _, _ = ob.assign(X, eps)
+    assert np.array_equal(np.diff(o_off), sizes)
+    for r in (0, 77, 255):
+        assert np.array_equal(np.asarray(X_set_inds[r]), o_inds[o_off[r]:o_off[r + 1]])
+    model = pmk.DeviceModel(X_set, [y[i] for i in X_set_inds])
+    model.fit(th, 1e-5)
+    assert np.all(model.info() == 0)
+    order = np.argsort(sizes, kind="stable")
+    for r in (int(order[0]), int(order[len(order) // 2]), int(order[-1])):
+        Xr, yr = X_set[r], y[X_set_inds[r]]
+        f = O.fit_patch(oth, Xr, yr, 1e-5, want_K=True)
+        assert f["info"] == 0
+        U = f["K"] + 1e-5 * np.eye(len(yr))
+        L, c = model.get(r, M.GET_L), model.get(r, M.GET_C)
+        assert np.all(np.triu(L, 1) == 0)
+        assert np.abs(L - f["L"]).max() <= 1e-8
+        assert np.linalg.norm(L @ L.T - U) / np.linalg.norm(U) <= 1e-14
+        assert np.linalg.norm(U @ c - yr) / (np.linalg.norm(U) * np.linalg.norm(c) + np.linalg.norm(yr)) <= 1e-13
+        assert np.linalg.norm(c - f["c_chol"]) / np.linalg.norm(f["c_chol"]) <= 1e-6
+    Nq = 50000
+    Xq = np.stack([rng.uniform(-5, 5, Nq), rng.uniform(-10, 10, Nq)], 1)
+    model.set_bsp(root, 0)
+    q = pmk.DeviceQuery(model, Xq)
+    q.plan(0.088, 1e-5); q.items(th); q.mix(wth)
+    Yq, Vq = q.fetch()
+    dbg = q.debug()
+    cache = {}
+    for j in rng.choice(Nq, 40, replace=False):
+        s = slice(dbg["item_offsets"][j], dbg["item_offsets"][j + 1])
+        us, vs = [], []
+        for r in dbg["item_region"][s]:
+            if r not in cache:
+                cache[r] = (model.get(int(r), M.GET_C), model.get(int(r), M.GET_L))
+            mu, var = O.queryinner(oth, X_set[r], cache[r][0], cache[r][1], Xq[j])
+            us.append(mu); vs.append(var)
+        ww = dbg["item_w"][s] / dbg["item_w"][s].sum()
+        yj, vj = ww @ np.array(us), ww @ (np.array(vs) * ww)
+        assert abs(Yq[j] - yj) <= 1e-7 * max(1, abs(yj)) and abs(Vq[j] - vj) <= 1e-9 + 1e-5 * vj
+
+
 # ------------------------------------------------------------------------------------ sharded predict (one process)
 def _sharded_predict_on_one_gpu(X_set, ys, root, Xq, world, th, wth, sigma2, radius, delta):
     """`world` models that each own a contiguous 1/world of the leaves and of the queries (what `world` ranks hold): the
