@@ -36,6 +36,9 @@ constexpr int PF_CHOL = 4;      // I-operand prefetch depth (k-steps) of the pan
 #endif
 constexpr int PFJ_CHOL = PMK_PFJ;   // J-operand (own rows, HBM) prefetch depth
 constexpr int PF_DIAG = 4;
+#ifdef PMK_CHOL_INDEXED
+#define gemm_nt gemm_nt_indexed
+#endif
 constexpr int SB = 32;          // sub-block of the in-LDS potrf and of the TRSM block substitution
 
 // LDS of a factorisation workgroup: first the TRSM operands of the block row (TRI_LDS_DOUBLES), later -- in the

@@ -24,21 +24,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// operand pair load: base points at element (index0, k0) of a column-major matrix whose rows are the
-// fragment index; lane reads indices index0 + 2 rho, +1 at column k0 + (l >> 4)
-__device__ __forceinline__ real2_t load_pair(const real *base, int64_t ld, int lane)
-{
-    return *reinterpret_cast<const real2_t *>(base + 2 * (lane & 15) + (int64_t)(lane >> 4) * ld);
-}
-
-// the same for an operand that only this wave reads (its own rows / strip columns): a streaming hint keeps it from
-// displacing the operand the workgroups of a patch or region share through L2 (prediction: -3.7 % with the hint,
-// same box; the strips' V traffic otherwise evicts the factor's block row between the strips that share it)
-__device__ __forceinline__ real2_t load_pair_stream(const real *base, int64_t ld, int lane)
-{
-    return __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(base + 2 * (lane & 15) + (int64_t)(lane >> 4) * ld));
-}
-
 template <int NPI, int NPJ>
 struct WaveTile {
     real4_t f[2 * NPI][2 * NPJ];
@@ -54,10 +39,22 @@ struct WaveTile {
 // t[I][J] += sum_{k < K} MI[I, k] * MJ[J, k]   (opI = &MI[I0, 0], opJ = &MJ[J0, 0]; both column-major
 // with the tile index along the contiguous dimension).  The two operands are prefetched into separate
 // register rings: the I operand is shared by the workgroups of a patch / region and comes from L2
-// (depth PFI k-steps), the J operand is this wave's own stream from HBM and needs the deeper ring (PFJ,
-// a multiple of PFI).  K must be a positive multiple of 4*PFJ.
+// (depth PFI k-steps), the J operand is this wave's own stream from HBM (depth PFJ, a multiple of PFI).
+// K must be a positive multiple of 4*PFJ.
 // NACT < NPI: only the first NACT index pairs of the I dimension are computed (the rest of the tile is known to be
 // zero: identity padding of the last block row).
+//
+// OVER-READ: the rings are refilled without a bounds test, so the routine LOADS (and never uses) up to PFI k-steps of
+// the I operand and PFJ k-steps of the J operand past K.  Every caller passes operands that lie inside a padded patch
+// slab / strip with at least that many columns (rows) behind K.
+//
+// Waits.  The loop relies on counted waits (s_waitcnt vmcnt(N): the loads of the last PF-1 k-steps stay in flight).
+// The wait at the loop head serves the entry from the prologue as well as the back edge, so the prologue must issue
+// its loads in the order the loop consumes them and the scheduler must not reorder them: left alone it moved the loads
+// of k-step 0 to the end of the prologue, the head wait became vmcnt(0), and every pass of the loop then waited for the
+// loads it had issued a few instructions earlier (a wave alone on its SIMD ran at 73 % of the MFMA rate instead of
+// 90 %; tools/gemm_probe.hip).  Each I slot is refilled right behind the MFMAs that consumed it, so the loads of a
+// k-step are spread over its 16 MFMAs instead of queueing behind the last one.
 template <int NPI, int NPJ, int PFI, int PFJ = PFI, int NACT = NPI>
 __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI,
                                         const real *opJ, int64_t ldJ, int K, int lane)
@@ -65,14 +62,80 @@ __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, 
     static_assert(PFJ % PFI == 0, "the J ring depth must be a multiple of the I ring depth");
     static_assert(NACT >= 1 && NACT <= NPI, "active pairs");
     real2_t ra[PFI][NACT], rb[PFJ][NPJ];
+    // the lane's element of the next k-step to load: indices 2 rho, 2 rho + 1 at column (lane >> 4)
+    const real *qI = opI + 2 * (lane & 15) + (int64_t)(lane >> 4) * ldI;
+    const real *qJ = opJ + 2 * (lane & 15) + (int64_t)(lane >> 4) * ldJ;
+    const int64_t sI = 4 * ldI, sJ = 4 * ldJ;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < PFI; ++s)
+    for (int s = 0; s < PFJ; ++s) {
+        if (s < PFI) {
 #pragma unroll
-        for (int pi = 0; pi < NACT; ++pi) ra[s][pi] = load_pair(opI + 32 * pi + (int64_t)(4 * s) * ldI, ldI, lane);
+            for (int pi = 0; pi < NACT; ++pi) ra[s][pi] = *reinterpret_cast<const real2_t *>(qI + 32 * pi);
+            qI += sI;
+        }
+        // the J operand is read by this wave only (its own rows / strip columns): a streaming hint keeps it from
+        // displacing the operand that the workgroups of a patch or region share through L2
 #pragma unroll
-    for (int s = 0; s < PFJ; ++s)
+        for (int pj = 0; pj < NPJ; ++pj) rb[s][pj] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(qJ + 32 * pj));
+        qJ += sJ;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int k0 = 0; k0 < K; k0 += 4 * PFJ) {
 #pragma unroll
-        for (int pj = 0; pj < NPJ; ++pj) rb[s][pj] = load_pair_stream(opJ + 32 * pj + (int64_t)(4 * s) * ldJ, ldJ, lane);
+        for (int s = 0; s < PFJ; ++s) {
+            const int si = s % PFI;
+#pragma unroll
+            for (int pi = 0; pi < NACT; ++pi) {
+#pragma unroll
+                for (int ei = 0; ei < 2; ++ei)
+#pragma unroll
+                    for (int pj = 0; pj < NPJ; ++pj)
+#pragma unroll
+                        for (int ej = 0; ej < 2; ++ej)
+                            t.f[2 * pi + ei][2 * pj + ej] =
+                                mfma_real(ra[si][pi][ei], rb[s][pj][ej], t.f[2 * pi + ei][2 * pj + ej]);
+                ra[si][pi] = *reinterpret_cast<const real2_t *>(qI + 32 * pi);
+                if (pi == NACT - 1) {
+#pragma unroll
+                    for (int pj = 0; pj < NPJ; ++pj)
+                        rb[s][pj] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(qJ + 32 * pj));
+                }
+                // without this fence the scheduler hoists every load of the k-step group to the loop head and doubles
+                // the operand registers (spills)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            qI += sI;
+            qJ += sJ;
+        }
+    }
+}
+
+// The same product with every ring address recomputed from the k index (clamped at the end: no over-read).  Costs a
+// few more address instructions per k-step but keeps no running pointers alive: the prediction kernel, which is out
+// of registers around its GEMM, gets spill reloads in front of the loop with the pointer form (and with them a
+// vmcnt(1) at the loop head); this form compiles there to clean counted waits.
+template <int NPI, int NPJ, int PFI, int PFJ = PFI, int NACT = NPI>
+__device__ __forceinline__ void gemm_nt_indexed(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI,
+                                                const real *opJ, int64_t ldJ, int K, int lane)
+{
+    static_assert(PFJ % PFI == 0, "the J ring depth must be a multiple of the I ring depth");
+    static_assert(NACT >= 1 && NACT <= NPI, "active pairs");
+    real2_t ra[PFI][NACT], rb[PFJ][NPJ];
+    const real *bI = opI + 2 * (lane & 15) + (int64_t)(lane >> 4) * ldI;
+    const real *bJ = opJ + 2 * (lane & 15) + (int64_t)(lane >> 4) * ldJ;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < PFJ; ++s) {
+        if (s < PFI) {
+#pragma unroll
+            for (int pi = 0; pi < NACT; ++pi) ra[s][pi] = *reinterpret_cast<const real2_t *>(bI + 32 * pi + (int64_t)(4 * s) * ldI);
+        }
+#pragma unroll
+        for (int pj = 0; pj < NPJ; ++pj)
+            rb[s][pj] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(bJ + 32 * pj + (int64_t)(4 * s) * ldJ));
+        __builtin_amdgcn_sched_barrier(0);
+    }
     for (int k0 = 0; k0 < K; k0 += 4 * PFJ) {
 #pragma unroll
         for (int s = 0; s < PFJ; ++s) {
@@ -92,11 +155,10 @@ __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, 
             ki = ki < K ? ki : K - 4;
             kj = kj < K ? kj : K - 4;
 #pragma unroll
-            for (int pi = 0; pi < NACT; ++pi) ra[si][pi] = load_pair(opI + 32 * pi + (int64_t)ki * ldI, ldI, lane);
+            for (int pi = 0; pi < NACT; ++pi) ra[si][pi] = *reinterpret_cast<const real2_t *>(bI + 32 * pi + (int64_t)ki * ldI);
 #pragma unroll
-            for (int pj = 0; pj < NPJ; ++pj) rb[s][pj] = load_pair_stream(opJ + 32 * pj + (int64_t)kj * ldJ, ldJ, lane);
-            // without this fence the scheduler hoists every load of the group to the loop head and doubles the
-            // operand registers (spills)
+            for (int pj = 0; pj < NPJ; ++pj)
+                rb[s][pj] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(bJ + 32 * pj + (int64_t)kj * ldJ));
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -79,7 +79,7 @@ __device__ __forceinline__ void strip_block_row(WaveTile<4, 1> &acc, const real 
     if (i > 0) {
         // order this wave's earlier strip stores before its loads of them
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                gemm_nt<4, 1, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
+                gemm_nt_indexed<4, 1, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
     }
 #ifdef PMK_TRACE
     if (i == PMK_TRACE_ROW && lane == 0 && blockIdx.x < 64 && g_row_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 2] != 0)

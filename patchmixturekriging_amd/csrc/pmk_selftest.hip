@@ -85,8 +85,11 @@ int pmk_selftest_gemm(pmk_ctx *ctx, int K, const double *MI, const double *MJ, d
     if (!ctx || !MI || !MJ || !C || K < 16 || K % 16) { set_error("pmk_selftest_gemm: bad argument"); return -1; }
     PMK_HIP(hipSetDevice(ctx->device));
     double *dI, *dJ, *dC;
-    PMK_HIP(hipMalloc((void **)&dI, sizeof(double) * 128 * K));
-    PMK_HIP(hipMalloc((void **)&dJ, sizeof(double) * 32 * K));
+    // gemm_nt loads (and ignores) up to 4 k-steps = 16 columns past K: pad the operands
+    PMK_HIP(hipMalloc((void **)&dI, sizeof(double) * 128 * (K + 16)));
+    PMK_HIP(hipMalloc((void **)&dJ, sizeof(double) * 32 * (K + 16)));
+    PMK_HIP(hipMemset(dI, 0, sizeof(double) * 128 * (K + 16)));
+    PMK_HIP(hipMemset(dJ, 0, sizeof(double) * 32 * (K + 16)));
     PMK_HIP(hipMalloc((void **)&dC, sizeof(double) * 128 * 32));
     PMK_HIP(hipMemcpy(dI, MI, sizeof(double) * 128 * K, hipMemcpyHostToDevice));
     PMK_HIP(hipMemcpy(dJ, MJ, sizeof(double) * 32 * K, hipMemcpyHostToDevice));

@@ -1,0 +1,168 @@
+// Inner-loop probe for the fp64 MFMA wave-tile GEMM (pmk_mfma.h: gemm_nt) with the operand placement of the
+// prediction strips: the I operand (a 128-row block row of a factor) is shared by the workgroups of an XCD and comes
+// from L2, the J operand (the wave's own 32 strip columns) is private and streams from HBM.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipatchmixturekriging_amd/csrc -Iinclude tools/gemm_probe.hip -o tools/gemm_probe
+//   tools/gemm_probe [K=1024] [reps=16]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "pmk_mfma.h"
+
+using namespace pmk;
+using namespace pmk::f64;
+
+// pointer-stepping variant: no per-step index clamp (the ring over-reads up to PF k-steps past K: callers guarantee
+// that memory exists), every I slot is refilled right behind the MFMAs that consumed it
+template <int NPI, int NPJ, int PFI, int PFJ, int NACT, int TOUCH = 0>
+__device__ __forceinline__ void gemm_v2(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI, const real *opJ, int64_t ldJ,
+                                        int K, int lane)
+{
+    real2_t ra[PFI][NACT], rb[PFJ][NPJ];
+    const real *qI = opI + 2 * (lane & 15) + (int64_t)(lane >> 4) * ldI;
+    const real *qJ = opJ + 2 * (lane & 15) + (int64_t)(lane >> 4) * ldJ;
+    const int64_t sI = 4 * ldI, sJ = 4 * ldJ;
+    // TOUCH > 0: this wave's share of the I operand's cache lines TOUCH k-steps ahead is pulled into L2 by SCALAR
+    // loads (lgkmcnt: they do not sit in the in-order vector-memory queue): wave w of the workgroup takes lines
+    // 4w .. 4w+3 of the 32 that a k-step covers (8 waves) -- results are never used
+    const real *tI = opI + (int64_t)TOUCH * sI;
+    const int tw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int junk = 0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < PFJ; ++s) {
+        if (s < PFI) {
+#pragma unroll
+            for (int pi = 0; pi < NACT; ++pi) ra[s][pi] = *reinterpret_cast<const real2_t *>(qI + 32 * pi);
+            qI += sI;
+        }
+#pragma unroll
+        for (int pj = 0; pj < NPJ; ++pj) rb[s][pj] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(qJ + 32 * pj));
+        qJ += sJ;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int k0 = 0; k0 < K; k0 += 4 * PFJ) {
+#pragma unroll
+        for (int s = 0; s < PFJ; ++s) {
+            const int si = s % PFI;
+#pragma unroll
+            for (int pi = 0; pi < NACT; ++pi) {
+#pragma unroll
+                for (int ei = 0; ei < 2; ++ei)
+#pragma unroll
+                    for (int pj = 0; pj < NPJ; ++pj)
+#pragma unroll
+                        for (int ej = 0; ej < 2; ++ej)
+                            t.f[2 * pi + ei][2 * pj + ej] = mfma_real(ra[si][pi][ei], rb[s][pj][ej], t.f[2 * pi + ei][2 * pj + ej]);
+                ra[si][pi] = *reinterpret_cast<const real2_t *>(qI + 32 * pi);
+                if (pi == NACT - 1) {
+#pragma unroll
+                    for (int pj = 0; pj < NPJ; ++pj)
+                        rb[s][pj] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(qJ + 32 * pj));
+                }
+                if (TOUCH && pi == 0) {
+                    // column (tw >> 1) of the k-step, rows 64 (tw & 1) .. +63: 4 lines of 128 B
+                    const real *tp = tI + (int64_t)(tw >> 1) * ldI + 64 * (tw & 1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)      // "+s": the register stays reserved while loads are in flight
+                        asm volatile("s_load_dword %0, %1, %2" : "+s"(junk) : "s"(tp), "n"(128 * u));
+                    tI += sI;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            qI += sI;
+            qJ += sJ;
+        }
+    }
+    if (TOUCH) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(junk));
+}
+
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void probe(const double *__restrict__ L, int64_t ld, int64_t region_stride,
+                                                const double *__restrict__ strips, int64_t strip_stride, int K, int reps,
+                                                double *__restrict__ sink)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *S = L + (int64_t)(blockIdx.x & 7) * region_stride;
+    const double *V0 = strips + (int64_t)blockIdx.x * strip_stride + 32 * wave;
+    WaveTile<4, 1> acc;
+    acc.zero();
+    for (int r = 0; r < reps; ++r) {
+        const double *Li = S + (int64_t)(r & 15) * 128;
+        const double *V = V0 + (int64_t)(r & 1) * 64 * 256;       // (a fixed J operand would be hoisted out of the loop)
+        if (VAR == 0) gemm_nt<4, 1, 4, 4, 4>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 1) gemm_v2<4, 1, 4, 4, 4>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 2) gemm_v2<4, 1, 4, 8, 4>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 3) gemm_nt<4, 1, 4, 8, 4>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 4) gemm_v2<4, 1, 2, 4, 4>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 5) gemm_v2<4, 1, 4, 4, 4, 12>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 6) gemm_v2<4, 1, 4, 8, 4, 12>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 7) gemm_v2<4, 1, 4, 8, 4, 24>(acc, Li, ld, V, 256, K, lane);
+        __syncthreads();
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) s += acc.f[i][j][0] + acc.f[i][j][1] + acc.f[i][j][2] + acc.f[i][j][3];
+    if (s == 123.456) sink[0] = s;
+}
+
+#define CK(x)                                                                         \
+    do {                                                                              \
+        hipError_t e = (x);                                                           \
+        if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } \
+    } while (0)
+
+template <int VAR>
+static void run(const char *name, int threads, const double *L, int64_t ld, int64_t rs, const double *strips, int64_t ss, int K,
+                int reps, double *sink, int nwg)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int it = 0; it < 4; ++it) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(probe<VAR>, dim3(nwg), dim3(threads), 0, 0, L, ld, rs, strips, ss, K, reps, sink);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (it > 0 && ms < best) best = ms;
+    }
+    const double flops = (double)nwg * (threads / 64) * reps * (K / 4) * 16.0 * 2048.0;
+    printf("%-44s %d waves/WG  %8.3f ms  %6.2f TFLOP/s  (%.1f %% of 78.6)\n", name, threads / 64, best, flops / best / 1e9,
+           flops / best / 1e9 / 78.6 * 100);
+}
+
+int main(int argc, char **argv)
+{
+    const int K = argc > 1 ? atoi(argv[1]) : 1024;
+    if (K < 64 || K > 1920 || K % 32) { printf("K must be a multiple of 32 in [64, 1920]\n"); return 1; }
+    const int reps = argc > 2 ? atoi(argv[2]) : 16;
+    const int64_t ld = 2048, rs = ld * 2048;
+    const int nwg = 256;
+    double *L, *strips, *sink;
+    const int64_t ss = 2048 * 256;
+    CK(hipMalloc(&L, sizeof(double) * rs * 8));
+    const int64_t slack = 512 * 256;          // the rings over-read up to 8 k-steps past K; V is offset by up to 64 rows
+    CK(hipMalloc(&strips, sizeof(double) * (ss * nwg + slack)));
+    CK(hipMalloc(&sink, 64));
+    CK(hipMemset(L, 0, sizeof(double) * rs * 8));
+    CK(hipMemset(strips, 0, sizeof(double) * (ss * nwg + slack)));
+    printf("K = %d, %d block rows per workgroup, 256 workgroups\n", K, reps);
+    for (int threads : {512, 256}) {
+        run<0>("shipped gemm_nt PFI 4 PFJ 4", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<3>("shipped gemm_nt PFI 4 PFJ 8", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<1>("pointer stepping, spread loads PFI 4 PFJ 4", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<2>("pointer stepping, spread loads PFI 4 PFJ 8", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<4>("pointer stepping, spread loads PFI 2 PFJ 4", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<5>("pointer stepping PFI 4 PFJ 4, L2 touch 12 ahead", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<6>("pointer stepping PFI 4 PFJ 8, L2 touch 12 ahead", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<7>("pointer stepping PFI 4 PFJ 8, L2 touch 24 ahead", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+    }
+    return 0;
+}
