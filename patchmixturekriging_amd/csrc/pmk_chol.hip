@@ -36,9 +36,6 @@ constexpr int PF_CHOL = 4;      // I-operand prefetch depth (k-steps) of the pan
 #endif
 constexpr int PFJ_CHOL = PMK_PFJ;   // J-operand (own rows, HBM) prefetch depth
 constexpr int PF_DIAG = 4;
-#ifdef PMK_CHOL_INDEXED
-#define gemm_nt gemm_nt_indexed
-#endif
 constexpr int SB = 32;          // sub-block of the in-LDS potrf and of the TRSM block substitution
 
 // LDS of a factorisation workgroup: first the TRSM operands of the block row (TRI_LDS_DOUBLES), later -- in the
@@ -692,41 +689,73 @@ __global__ __launch_bounds__(1024) void chol_backsolve_kernel(const PatchDesc *_
                 Nt[sb * (SB * LDN) + i + c * LDN] = nv[u];
             }
         }
-        // r[col] = z_k[col] - sum_{i >= d0 + TILE} L[i, d0 + col] c[i]: one wave per column, coalesced rows
+        // r[col] = z_k[col] - sum_{i >= d0 + TILE} L[i, d0 + col] c[i]: a wave takes two columns at a time (cc, cc + 16)
+        // and four 128-row chunks of each, 16-byte loads: eight 1 KiB loads in flight per wave (the loop used to keep
+        // four 512-byte loads in flight and wait for all of them every pass -- latency bound at 4 TB/s)
         const int64_t i0 = d0 + TILE;
-        for (int cc = wave; cc < TILE; cc += 16) {
-            const real *col = S + (d0 + cc) * ld;
-            real s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int64_t i = i0 + lane;
-            for (; i + 192 < ld; i += 256) {
-                s0 += col[i] * cs[i];
-                s1 += col[i + 64] * cs[i + 64];
-                s2 += col[i + 128] * cs[i + 128];
-                s3 += col[i + 192] * cs[i + 192];
-            }
-            for (; i < ld; i += 64) s0 += col[i] * cs[i];
-            real s = (s0 + s1) + (s2 + s3);
+        const int nrow = (int)(ld - i0);                       // a multiple of TILE
+        for (int cc = wave; cc < TILE; cc += 32) {
+            const real *colA = S + (d0 + cc) * ld + i0, *colB = colA + 16 * ld;
+            const real *cp = cs + i0;
+            real2_t sA[4], sB[4];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) r[cc] = z[pd.yoff + d0 + cc] - s;
+            for (int u = 0; u < 4; ++u) sA[u] = sB[u] = real2_t{0, 0};
+            int i = 2 * lane;
+            for (; i + 384 < nrow; i += 512) {
+                real2_t a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(colA + i + 128 * u));
+                    b[u] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(colB + i + 128 * u));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const real2_t c = *reinterpret_cast<const real2_t *>(cp + i + 128 * u);
+                    sA[u] += a[u] * c;
+                    sB[u] += b[u] * c;
+                }
+            }
+            for (; i < nrow; i += 128) {
+                const real2_t a = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(colA + i));
+                const real2_t b = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(colB + i));
+                const real2_t c = *reinterpret_cast<const real2_t *>(cp + i);
+                sA[0] += a * c;
+                sB[0] += b * c;
+            }
+            const real2_t tA = (sA[0] + sA[1]) + (sA[2] + sA[3]), tB = (sB[0] + sB[1]) + (sB[2] + sB[3]);
+            real vA = tA[0] + tA[1], vB = tB[0] + tB[1];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                vA += __shfl_xor(vA, o);
+                vB += __shfl_xor(vB, o);
+            }
+            if (lane == 0) {
+                r[cc] = z[pd.yoff + d0 + cc] - vA;
+                r[cc + 16] = z[pd.yoff + d0 + cc + 16] - vB;
+            }
         }
         __syncthreads();
-        // c_k = L[kk]^-T r by block backward substitution with the negated inverted 32 x 32 blocks, all from LDS
+        // c_k = L[kk]^-T r by block backward substitution with the negated inverted 32 x 32 blocks, all from LDS.
+        // Both products of a stage are spread over the 16 waves: a wave owns columns 2 wave and 2 wave + 1 (one per
+        // half wave), a lane one row of the 32-row block, and the 32 partial products meet in a shuffle reduction
+        // (one thread per column walking 96 + 32 LDS entries was ~10 us of serial work per block row).
+        const int hcol = 2 * wave + (lane >> 5), hl = lane & 31;
         for (int s = 3; s >= 0; --s) {
-            if (tid < SB) {
-                const int col = SB * s + tid;
-                real v = r[col];
-                for (int bi = s + 1; bi < 4; ++bi) {
-                    const real *blk = Lt + (bi * (bi - 1) / 2 + s) * (SB * LDN) + tid * LDN;
-                    for (int i = 0; i < SB; ++i) v -= blk[i] * cs[d0 + SB * bi + i];
-                }
-                r[col] = v;
+            {
+                real v = 0.0;
+                for (int bi = s + 1; bi < 4; ++bi)
+                    v += Lt[(bi * (bi - 1) / 2 + s) * (SB * LDN) + hcol * LDN + hl] * cs[d0 + SB * bi + hl];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                if (hl == 0 && s < 3) r[SB * s + hcol] -= v;
             }
             __syncthreads();
-            if (tid < SB) {
-                real v = 0.0;
-                for (int i = tid; i < SB; ++i) v -= Nt[s * (SB * LDN) + i + tid * LDN] * r[SB * s + i];   // D^-T r
-                cs[d0 + SB * s + tid] = v;
+            {
+                // (D^-T r)[hcol] = sum_{i >= hcol} Ninv[i][hcol] r[i], negated inverse stored
+                real v = hl >= hcol ? Nt[s * (SB * LDN) + hl + hcol * LDN] * r[SB * s + hl] : (real)0;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                if (hl == 0) cs[d0 + SB * s + hcol] = -v;
             }
             __threadfence_block();
             __syncthreads();
