@@ -18,8 +18,9 @@ extern "C" {
 /* C[I][J] (128 x 32, J contiguous: C[J + 32*I]) = sum_k MI[I + 128 k] MJ[J + 32 k],
  * k < K (K a multiple of 16), through gemm_nt<4,1,4> of one wave.  Host buffers. */
 int pmk_selftest_gemm(pmk_ctx *ctx, int K, const double *MI, const double *MJ, double *C);
-/* T (128 x 32, T[J + 32*I]) <- -L^-1 T through tri_solve_inplace: L is 128 x 128 column-major lower,
- * ninv its four negated inverted 32 x 32 diagonal blocks (column-major, ld 32) */
+/* T (128 x 32, T[J + 32*I]) <- -L^-1 T through tri_solve_inplace (operands staged in LDS) AND tri_solve_global (operands
+ * prefetched from global memory); elements on which the two disagree come back as NaN.  L is 128 x 128 column-major
+ * lower, ninv its four negated inverted 32 x 32 diagonal blocks (column-major, ld 32) */
 int pmk_selftest_trisolve(pmk_ctx *ctx, const double *L, const double *ninv, const double *T_in, double *T_out);
 /* sustained fp64 MFMA rate of the device in TFLOP/s (register-resident loop, all CUs) */
 int pmk_selftest_mfma_peak(pmk_ctx *ctx, double *tflops);

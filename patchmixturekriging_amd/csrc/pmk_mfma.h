@@ -24,6 +24,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// wave-uniform values that the compiler cannot prove uniform (loaded through a lane-indexed path): move them to
+// scalar registers so that address arithmetic on them runs on the scalar unit
+__device__ __forceinline__ int64_t uniform_i64(int64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ const T *uniform_ptr(const T *p)
+{
+    return reinterpret_cast<const T *>(uniform_i64(reinterpret_cast<int64_t>(p)));
+}
+
 template <int NPI, int NPJ>
 struct WaveTile {
     real4_t f[2 * NPI][2 * NPJ];
@@ -256,6 +270,83 @@ __device__ __forceinline__ void tri_solve_inplace(WaveTile<4, NPJ> &t, const rea
         for (int j = 0; j < 2 * NPJ; ++j) {
             t.f[2 * s + 0][j] = o[0][j];
             t.f[2 * s + 1][j] = o[1][j];
+        }
+    }
+}
+
+// The same block substitution with its operands taken straight from global memory (the factor's diagonal tile in the
+// slab, leading dimension ldl, and its four negated inverted 32 x 32 blocks at ninv, leading dimension 32) instead
+// of an LDS copy: the ten 32 x 32 operand blocks are visited in the order of use and the 8 fragment loads of block
+// b + 1 are issued before the 32 MFMAs of block b, so no load sits inside a dependent stage.  For callers that cannot
+// afford the 80 KiB LDS copy or the barrier around staging it (prediction strips).
+template <int NPJ>
+__device__ __forceinline__ void tri_solve_global(WaveTile<4, NPJ> &t, const real *L, int64_t ldl, const real *ninv, int lane)
+{
+    // block list in order of use: s = 0: D0 | s = 1: (1,0) D1 | s = 2: (2,0) (2,1) D2 | s = 3: (3,0) (3,1) (3,2) D3
+    // Addresses: a wave-uniform base (scalar registers; readfirstlane tells the compiler so) plus one 32-bit byte
+    // offset per lane and operand -- written as 80 independent 64-bit lane addresses the compiler computed all of them
+    // up front and spilled half the register file.
+    // k index of fragment register (q, e) for this lane: 2 frag_irow(lane >> 4, q) + e = lane part + uniform part
+    const uint32_t offL = (uint32_t)((2 * (lane & 15) + (int64_t)(2 * frag_irow(lane >> 4, 0)) * ldl) * (int64_t)sizeof(real));
+    const uint32_t offN = (uint32_t)((2 * (lane & 15) + 32 * (2 * frag_irow(lane >> 4, 0))) * (int)sizeof(real));
+    const char *Lb = uniform_ptr(reinterpret_cast<const char *>(L));
+    const char *Nb = uniform_ptr(reinterpret_cast<const char *>(ninv));
+    const int64_t ldu = uniform_i64(ldl);
+    auto fetch = [&](real2_t (&dst)[8], int s, int pj) {        // pj == s: the inverted diagonal block
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ku = 2 * frag_irow(0, q) + e;          // uniform part of the k index
+                dst[2 * q + e] =
+                    (pj == s) ? *reinterpret_cast<const real2_t *>(Nb + (int64_t)(1024 * s + 32 * ku) * (int64_t)sizeof(real) + offN)
+                              : *reinterpret_cast<const real2_t *>(Lb + (32 * s + (int64_t)(32 * pj + ku) * ldu) * (int64_t)sizeof(real) + offL);
+            }
+    };
+    real2_t ring[2][8];
+    fetch(ring[0], 0, 0);
+    int b = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int pj = 0; pj <= s; ++pj, ++b) {
+            // next block in the list
+            const int ns = (pj == s) ? s + 1 : s, npj = (pj == s) ? 0 : pj + 1;
+            if (ns < 4) fetch(ring[(b + 1) & 1], ns, npj);
+            __builtin_amdgcn_sched_barrier(0);
+            const real2_t(&a)[8] = ring[b & 1];
+            if (pj < s) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int j = 0; j < 2 * NPJ; ++j) {
+                            t.f[2 * s + 0][j] = mfma_real(a[2 * q + e][0], t.f[2 * pj + e][j][q], t.f[2 * s + 0][j]);
+                            t.f[2 * s + 1][j] = mfma_real(a[2 * q + e][1], t.f[2 * pj + e][j][q], t.f[2 * s + 1][j]);
+                        }
+            } else {
+                real4_t o[2][2 * NPJ];
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int j = 0; j < 2 * NPJ; ++j) o[e][j] = real4_t{0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int j = 0; j < 2 * NPJ; ++j) {
+                            o[0][j] = mfma_real(a[2 * q + e][0], t.f[2 * s + e][j][q], o[0][j]);
+                            o[1][j] = mfma_real(a[2 * q + e][1], t.f[2 * s + e][j][q], o[1][j]);
+                        }
+#pragma unroll
+                for (int j = 0; j < 2 * NPJ; ++j) {
+                    t.f[2 * s + 0][j] = o[0][j];
+                    t.f[2 * s + 1][j] = o[1][j];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }

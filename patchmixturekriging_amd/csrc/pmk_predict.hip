@@ -57,10 +57,12 @@ __device__ unsigned long long g_row_stamp[512 * 40];
 #define PMK_PSTAMP(k)                                                                                        \
     do {                                                                                                     \
         if (round == PMK_TRACE_ROUND && i == PMK_TRACE_ROW && lane == 0 && blockIdx.x < 64)                   \
-            g_row_stamp[(blockIdx.x * 8 + wave) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();               \
+            g_row_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();               \
     } while (0)
+#define PMK_TRACED (round == PMK_TRACE_ROUND)
 #else
 #define PMK_PSTAMP(k)
+#define PMK_TRACED false
 #endif
 
 struct StripTask {
@@ -74,20 +76,79 @@ struct StripTask {
 // one block row of the strip: acc = Kq_i (in) -> -V_i (out)
 template <int NACT>
 __device__ __forceinline__ void strip_block_row(WaveTile<4, 1> &acc, const real *Li, int64_t ld, const real *V, int i,
-                                                const real *tri, int lane)
+                                                const real *Lii, const real *ninv_i, int lane, bool traced = false)
 {
     if (i > 0) {
         // order this wave's earlier strip stores before its loads of them
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                gemm_nt_indexed<4, 1, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
+        gemm_nt_indexed<4, 1, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
     }
 #ifdef PMK_TRACE
-    if (i == PMK_TRACE_ROW && lane == 0 && blockIdx.x < 64 && g_row_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 2] != 0)
+    if (traced && i == PMK_TRACE_ROW && lane == 0 && blockIdx.x < 64) {
         g_row_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        g_row_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 7] = __builtin_amdgcn_s_memtime();      // shader clock
+    }
 #endif
-    tri_solve_inplace<1>(acc, tri, lane);
+    // the TRSM operands come straight from the factor (prefetched block by block into registers): no LDS copy, no
+    // barrier around staging one
+    tri_solve_global<1>(acc, Lii, ld, ninv_i, lane);
 }
 
+// Kq tile of one block row (query is the first kernel argument, mixtureGP.jl:304) into the wave's accumulator, 32 rows
+// at a time in a ROLLED loop whose results pass through a lane-private LDS slot: fully unrolled, the 64 evaluations
+// of a tile and the accumulator they fill were allocated hundreds of spilled registers (scratch traffic was a quarter
+// of this kernel's HBM bytes) and 3 k instructions of code per block row.  Adds the tile's share of the mean.
+template <int D, int FAM>
+__device__ __forceinline__ void eval_tile(WaveTile<4, 1> &acc, const real *pt, real2_t *mine, real *pk, const pmk_kernel_desc &th,
+                                          int row0, int n, int lane)
+{
+    // the lane's two query points and running means live in its LDS park between block rows (see the kernel)
+    real q[2][D], mu[2];
+#pragma unroll
+    for (int ej = 0; ej < 2; ++ej) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) q[ej][d] = pk[(ej * D + d) * PRED_THREADS];
+        mu[ej] = pk[(2 * D + ej) * PRED_THREADS];
+    }
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi) {
+#pragma clang loop unroll_count(2)
+        for (int sl = 0; sl < 8; ++sl) {
+            const int r = 32 * pi + 2 * frag_irow(lane >> 4, sl >> 1) + (sl & 1);     // row within the block row
+            real xr[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) xr[d] = pt[d * TILE + r];
+            const real cw = pt[D * TILE + r];
+            // padding rows carry coordinates of 1e300 (pack_soa): a compactly supported profile is
+            // exactly 0 there, so the Spline34 instantiation needs no bounds test
+            const bool inside = (FAM == PMK_SPLINE34) || row0 + r < n;
+            real2_t kv;
+            kv[0] = inside ? kern_eval<D, FAM, real>(th, q[0], xr) : (real)0;
+            kv[1] = inside ? kern_eval<D, FAM, real>(th, q[1], xr) : (real)0;
+            mu[0] += kv[0] * cw;
+            mu[1] += kv[1] * cw;
+            mine[sl * 64] = kv;
+        }
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            const real2_t kv = mine[sl * 64];
+            acc.f[2 * pi + (sl & 1)][0][sl >> 1] = kv[0];
+            acc.f[2 * pi + (sl & 1)][1][sl >> 1] = kv[1];
+        }
+    }
+    pk[(2 * D + 0) * PRED_THREADS] = mu[0];
+    pk[(2 * D + 1) * PRED_THREADS] = mu[1];
+}
+
+// Schedule of a strip.  One barrier per block row.  Everything that is not an MFMA is kept off the critical path:
+//  * the block row's training points are staged into a three-deep LDS ring two block rows ahead;
+//  * the TRSM operands are prefetched from the factor into registers (tri_solve_global);
+//  * of the two waves that share a SIMD the older one (waves 0..3) gets most of the matrix pipe and finishes its
+//    block row ~100 us before the younger one (waves 4..7).  The older wave evaluates its NEXT kernel tile in that
+//    idle time, before the barrier; the younger wave evaluates its tile after the barrier, while the older wave --
+//    which has the pipe anyway -- is already in its GEMM.  Both evaluations run in the shadow of the other wave's MFMAs;
+//  * the lock-step rendezvous with the other strips of the region is split-phase: thread 0 (wave 0, an early
+//    finisher) arrives for the next block row and spins, bounded, before the barrier.
 template <int D, int FAM>
 __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const PatchDesc *__restrict__ descs,
                                                                const real *__restrict__ x, const real *__restrict__ A,
@@ -102,9 +163,15 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     real *V = strips + (int64_t)blockIdx.x * strip_stride + 32 * wave;   // this wave's 32 columns, ld = TQ
-    __shared__ real tri[TRI_LDS_DOUBLES];     // TRSM operands of the current block row (shared by the 8 waves)
-    __shared__ real pts[(MAX_D + 1) * TILE];  // the block row's training points (SoA) and weights
+    constexpr int PTS = (MAX_D + 1) * TILE;
+    __shared__ real pts[3 * PTS];             // training points (SoA) and weights of three consecutive block rows
     __shared__ real priv[PRED_WAVES * 8 * 64 * 2];   // lane-private staging of the kernel evaluations (8 slots a lane)
+    real2_t *mine = reinterpret_cast<real2_t *>(priv) + (wave * 8) * 64 + lane;
+    // Per-thread values that are only needed between the MFMA phases (the two query points, the running means and
+    // squared norms) are PARKED in LDS: around its GEMM the kernel has no register to spare (128 accumulator + 80 ring
+    // registers of 256), and what the compiler spills instead goes to scratch memory, in the middle of the hot loops.
+    __shared__ real park[(2 * MAX_D + 4) * PRED_THREADS];
+    real *pk = park + threadIdx.x;      // slot k of this thread: pk[k * PRED_THREADS]
 
     // XCD-aware task order: the workgroups of one XCD take consecutive tasks (= strips of the same
     // region, which stream the same factor L) so that L is fetched into one L2 once per region
@@ -131,137 +198,131 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
         }
         const int task = base + xcd_remap(blockIdx.x, nin);
         const StripTask tk = tasks[task];
-        const bool active = 32 * wave < tk.count;     // wave-uniform; idle waves still help stage operands
+        const bool active = 32 * wave < tk.count;     // wave-uniform
         const PatchDesc pd = descs[tk.region];
         const real *S = A + pd.aoff;
         const real *xs = x + pd.xoff;
         const real *cr = cvec + pd.yoff;
         const int64_t ld = pd.ld;
 
-        // the lane's 2 query columns: 2 (lane & 15) + ej of the wave's 32
-        real q[2][D];
-        int64_t pos[2];
-        bool valid[2];
+        // lock-step rendezvous of the strips that share this factor on this XCD (speed only: a bounded spin on an
+        // arrival counter, no data is handed over): thread 0 arrives for block row `row` and waits for the others
+        auto rendezvous = [&](int row) {
+            uint32_t *cnt = sync_cnt + tk.group;
+            const uint32_t want = (uint32_t)tk.gsize * (uint32_t)(row + 1);
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
+                   __builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)PMK_SYNC_TICKS)
+                __builtin_amdgcn_s_sleep(8);
+#ifdef PMK_TRACE
+            const unsigned long long w = __builtin_amdgcn_s_memrealtime() - t0;
+            atomicAdd(&g_sync_stats[0], 1ull);
+            if (w >= (unsigned long long)PMK_SYNC_TICKS) atomicAdd(&g_sync_stats[1], 1ull);
+            atomicAdd(&g_sync_stats[2], w);
+            atomicMax(&g_sync_stats[3], w);
+#endif
+        };
+        // the training points and weights of block row `br`, the same for every lane of the workgroup, by 128 threads
+        auto stage_points = [&](int br, int t) {
+            real *dst = pts + (br % 3) * PTS;
+            const int row = br * TILE + t;
+#pragma unroll
+            for (int d = 0; d < D; ++d) dst[d * TILE + t] = xs[(int64_t)d * ld + row];
+            dst[D * TILE + t] = cr[row];
+        };
+
+        // the lane's 2 query columns: 2 (lane & 15) + ej of the wave's 32 (padding columns repeat a valid item)
 #pragma unroll
         for (int ej = 0; ej < 2; ++ej) {
             const int col = 32 * wave + 2 * (lane & 15) + ej;
-            valid[ej] = col < tk.count;
-            pos[ej] = tk.first + (valid[ej] ? col : 0);                // padding columns repeat a valid item
-            const int64_t qi = item_query[sorted_item[pos[ej]]];
+            const int64_t p = tk.first + (col < tk.count ? col : 0);
+            const int64_t qi = item_query[sorted_item[p]];
 #pragma unroll
-            for (int d = 0; d < D; ++d) q[ej][d] = (real)xq[qi * D + d];
+            for (int d = 0; d < D; ++d) pk[(ej * D + d) * PRED_THREADS] = (real)xq[qi * D + d];
+            pk[(2 * D + ej) * PRED_THREADS] = (real)0;           // mean
+            pk[(2 * D + 2 + ej) * PRED_THREADS] = (real)0;       // |V|^2
         }
-        real mu[2] = {0.0, 0.0}, vs[2] = {0.0, 0.0};
         // rows of the last block row that are not identity padding, in 32-row pairs (n = 2000: 3 of 4)
         const int last_pairs = (pd.n - (pd.nt - 1) * TILE + 31) >> 5;
 
+        __syncthreads();                              // every wave is done with the previous task's points
+        if (threadIdx.x < 2 * TILE && (int)(threadIdx.x >> 7) < pd.nt) stage_points(threadIdx.x >> 7, threadIdx.x & (TILE - 1));
+        if (threadIdx.x == 0 && tk.group >= 0) rendezvous(0);
+        WaveTile<4, 1> acc;
+        bool have = false;                            // acc already holds this block row's kernel tile
         for (int i = 0; i < pd.nt; ++i) {
-            __syncthreads();                          // every wave is done with the previous block row's operands
+            __syncthreads();                          // block row i - 1 is complete in every wave; points of row i, i + 1 visible
             PMK_PSTAMP(0);
-            if (threadIdx.x == 0 && tk.group >= 0) {
-                // lock-step rendezvous of the strips that share this factor on this XCD (speed only)
-                uint32_t *cnt = sync_cnt + tk.group;
-                const uint32_t want = (uint32_t)tk.gsize * (uint32_t)(i + 1);
-                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
-                       __builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)PMK_SYNC_TICKS)
-                    __builtin_amdgcn_s_sleep(8);
+            if (threadIdx.x < TILE && i + 2 < pd.nt) stage_points(i + 2, threadIdx.x);
+            if (active) {
+                if (!have) eval_tile<D, FAM>(acc, pts + (i % 3) * PTS, mine, pk, th, i * TILE, pd.n, lane);
+                PMK_PSTAMP(2);
 #ifdef PMK_TRACE
-                const unsigned long long w = __builtin_amdgcn_s_memrealtime() - t0;
-                atomicAdd(&g_sync_stats[0], 1ull);
-                if (w >= (unsigned long long)PMK_SYNC_TICKS) atomicAdd(&g_sync_stats[1], 1ull);
-                atomicAdd(&g_sync_stats[2], w);
-                atomicMax(&g_sync_stats[3], w);
+                if (round == PMK_TRACE_ROUND && i == PMK_TRACE_ROW && lane == 0 && blockIdx.x < 64)
+                    g_row_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 1] = __builtin_amdgcn_s_memtime();
 #endif
-            }
-            stage_tri_operands(tri, S + (int64_t)i * TILE + (int64_t)i * TILE * ld, ld, inv + pd.ioff + (int64_t)i * 4096,
-                               threadIdx.x, PRED_THREADS);
-            // the block row's training points and weights, the same for every lane of the workgroup
-            if (threadIdx.x < TILE) {
-                const int row = i * TILE + threadIdx.x;
+                // ---- acc -= L[i, 0:i] V_0:i  (the strip holds -V), then acc <- -V_i = -L[ii]^-1 acc (block substitution;
+                //      the strip wants -V anyway).  Padding rows of the last block row are zero and stay zero: skip them.
+                const real *Li = S + (int64_t)i * TILE;
+                const real *Lii = Li + (int64_t)i * TILE * ld;
+                const real *ninv_i = inv + pd.ioff + (int64_t)i * 4096;
+                if (i + 1 == pd.nt && last_pairs == 3) strip_block_row<3>(acc, Li, ld, V, i, Lii, ninv_i, lane, PMK_TRACED);
+                else if (i + 1 == pd.nt && last_pairs == 2) strip_block_row<2>(acc, Li, ld, V, i, Lii, ninv_i, lane, PMK_TRACED);
+                else if (i + 1 == pd.nt && last_pairs == 1) strip_block_row<1>(acc, Li, ld, V, i, Lii, ninv_i, lane, PMK_TRACED);
+                else strip_block_row<4>(acc, Li, ld, V, i, Lii, ninv_i, lane, PMK_TRACED);
+                PMK_PSTAMP(4);
+                {
+                    real vs[2] = {pk[(2 * D + 2) * PRED_THREADS], pk[(2 * D + 3) * PRED_THREADS]};
 #pragma unroll
-                for (int d = 0; d < D; ++d) pts[d * TILE + threadIdx.x] = xs[(int64_t)d * ld + row];
-                pts[D * TILE + threadIdx.x] = cr[row];
-            }
-            __syncthreads();
-            PMK_PSTAMP(1);
-            if (!active) continue;
-            WaveTile<4, 1> acc;
-            // ---- Kq tile for block row i (query is the first kernel argument, mixtureGP.jl:304), 32 rows at a time in a
-            //      ROLLED loop whose results pass through a lane-private LDS slot: fully unrolled, the 64 evaluations of a
-            //      tile and the accumulator they fill were allocated hundreds of spilled registers (scratch traffic was a
-            //      quarter of this kernel's HBM bytes) and 3 k instructions of code per block row
-            real2_t *mine = reinterpret_cast<real2_t *>(priv) + (wave * 8) * 64 + lane;
+                    for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
-            for (int pi = 0; pi < 4; ++pi) {
-#pragma clang loop unroll_count(2)
-                for (int sl = 0; sl < 8; ++sl) {
-                    const int r = 32 * pi + 2 * frag_irow(lane >> 4, sl >> 1) + (sl & 1);     // row within the block row
-                    real xr[D];
+                        for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-                    for (int d = 0; d < D; ++d) xr[d] = pts[d * TILE + r];
-                    const real cw = pts[D * TILE + r];
-                    // padding rows carry coordinates of 1e300 (pack_soa): a compactly supported profile is
-                    // exactly 0 there, so the Spline34 instantiation needs no bounds test
-                    const bool inside = (FAM == PMK_SPLINE34) || i * TILE + r < pd.n;
-                    real2_t kv;
-                    kv[0] = inside ? kern_eval<D, FAM, real>(th, q[0], xr) : (real)0;
-                    kv[1] = inside ? kern_eval<D, FAM, real>(th, q[1], xr) : (real)0;
-                    mu[0] += kv[0] * cw;
-                    mu[1] += kv[1] * cw;
-                    mine[sl * 64] = kv;
+                            for (int ej = 0; ej < 2; ++ej) vs[ej] += acc.f[fi][ej][qq] * acc.f[fi][ej][qq];
+                    pk[(2 * D + 2) * PRED_THREADS] = vs[0];
+                    pk[(2 * D + 3) * PRED_THREADS] = vs[1];
                 }
+                have = false;
+                if (i + 1 < pd.nt) {
+                    int srow = tile_i(0, lane, 0);
+                    asm volatile("" : "+v"(srow));
 #pragma unroll
-                for (int sl = 0; sl < 8; ++sl) {
-                    const real2_t kv = mine[sl * 64];
-                    acc.f[2 * pi + (sl & 1)][0][sl >> 1] = kv[0];
-                    acc.f[2 * pi + (sl & 1)][1][sl >> 1] = kv[1];
-                }
-            }
-            PMK_PSTAMP(2);
-            // ---- acc -= L[i, 0:i] V_0:i  (the strip holds -V), then acc <- -V_i = -L[ii]^-1 acc (block substitution;
-            //      the strip wants -V anyway).  Padding rows of the last block row are zero and stay zero: skip them.
-            const real *Li = S + (int64_t)i * TILE;
-            if (i + 1 == pd.nt && last_pairs == 3) strip_block_row<3>(acc, Li, ld, V, i, tri, lane);
-            else if (i + 1 == pd.nt && last_pairs == 2) strip_block_row<2>(acc, Li, ld, V, i, tri, lane);
-            else if (i + 1 == pd.nt && last_pairs == 1) strip_block_row<1>(acc, Li, ld, V, i, tri, lane);
-            else strip_block_row<4>(acc, Li, ld, V, i, tri, lane);
-            PMK_PSTAMP(4);
+                    for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
-            for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-                    for (int ej = 0; ej < 2; ++ej) vs[ej] += acc.f[fi][ej][qq] * acc.f[fi][ej][qq];
-            if (i + 1 < pd.nt) {
-                int srow = tile_i(0, lane, 0);
-                asm volatile("" : "+v"(srow));
-#pragma unroll
-                for (int fi = 0; fi < 8; ++fi)
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const int row = i * TILE + srow + (tile_i(fi, 0, qq) - tile_i(0, 0, 0));
-                        real2_t o;
-                        o[0] = acc.f[fi][0][qq];
-                        o[1] = acc.f[fi][1][qq];
-                        __builtin_nontemporal_store(o, reinterpret_cast<real2_t *>(V + (int64_t)row * TQ + 2 * (lane & 15)));
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const int row = i * TILE + srow + (tile_i(fi, 0, qq) - tile_i(0, 0, 0));
+                            real2_t o;
+                            o[0] = acc.f[fi][0][qq];
+                            o[1] = acc.f[fi][1][qq];
+                            __builtin_nontemporal_store(o, reinterpret_cast<real2_t *>(V + (int64_t)row * TQ + 2 * (lane & 15)));
+                        }
+                    PMK_PSTAMP(5);
+                    if (wave < PRED_WAVES / 2) {      // the older wave of its SIMD: next tile now, in its idle time
+                        eval_tile<D, FAM>(acc, pts + ((i + 1) % 3) * PTS, mine, pk, th, (i + 1) * TILE, pd.n, lane);
+                        have = true;
                     }
+                }
+                PMK_PSTAMP(6);
             }
-            PMK_PSTAMP(5);
+            if (threadIdx.x == 0 && tk.group >= 0 && i + 1 < pd.nt) rendezvous(i + 1);
         }
         // ---- reduce over the four lane groups that share a column, then write (u, v)
 #pragma unroll
         for (int ej = 0; ej < 2 && active; ++ej) {
-            real a = mu[ej], b = vs[ej];
+            real a = pk[(2 * D + ej) * PRED_THREADS], b = pk[(2 * D + 2 + ej) * PRED_THREADS];
             a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
             a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-            if ((lane >> 4) == 0 && valid[ej]) {
-                const real kself = kern_eval<D, FAM, real>(th, q[ej], q[ej]);
+            const int col = 32 * wave + 2 * (lane & 15) + ej;
+            if ((lane >> 4) == 0 && col < tk.count) {
+                real qe[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) qe[d] = pk[(ej * D + d) * PRED_THREADS];
+                const real kself = kern_eval<D, FAM, real>(th, qe, qe);
                 double var = (double)kself - (double)b;               // mixtureGP.jl:312
                 var = var < min_v ? min_v : var;                     // clamp(..., min_v, Inf)
-                u_out[pos[ej]] = (double)a;
-                v_out[pos[ej]] = var;
+                u_out[tk.first + col] = (double)a;
+                v_out[tk.first + col] = var;
             }
         }
         // the next task reuses the strip: order its first stores after this task's last loads

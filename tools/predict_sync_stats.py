@@ -45,19 +45,21 @@ def main():
     buf = np.zeros(512 * 40, dtype=np.uint64)
     L.pmk_trace_sync_stats(buf.ctypes.data_as(C.c_void_p), 2)
     t = buf[:64 * 8 * 8].reshape(64, 8, 8).astype(np.float64) / 100.0          # [wg][wave][stamp] in us
-    ok = t[:, :, 5].min(axis=1) > 0
+    ok = (t[:, :, 4].min(axis=1) > 0) & (t[:, :, 0].min(axis=1) > 0)
     t = t[ok]
-    print("phase timeline of one block row (traced row/round are compile-time), %d workgroups, us:" % len(t))
-    names = ["rendezvous+staging", "kernel tile (VALU)", "GEMM", "TRSM", "norms + V store"]
-    for k, nm in enumerate(names):
-        d = t[:, :, k + 1] - t[:, :, k]
-        print("  %-20s med %.1f  p10 %.1f  p90 %.1f" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
-    tot = t[:, :, 5] - t[:, :, 0]
-    print("  %-20s med %.1f" % ("whole block row", np.median(tot)))
-    w0 = t[:, :, 5].max(axis=1) - t[:, :, 5].min(axis=1)
-    print("  spread of the 8 waves' finish times within a workgroup: med %.1f us" % np.median(w0))
+    print("timeline of one block row (traced row / round are compile-time), %d workgroups; us after the barrier, median over" % len(t))
+    print("workgroups; stamps: 0 barrier passed, 2 kernel tile ready, 3 GEMM done, 4 TRSM done, 5 V stored, 6 next tile pre-evaluated")
+    t0 = t[:, :, 0].min(axis=1)[:, None]
     for w in range(8):
-        print("   wave %d: GEMM med %.1f us, ends at +%.1f us" % (w, np.median(t[:, w, 3] - t[:, w, 2]), np.median(t[:, w, 5] - t[:, :, 0].min(axis=1))))
+        row = []
+        for k in (0, 2, 3, 4, 5, 6):
+            v = t[:, w, k]
+            row.append("%7.1f" % np.median(v - t0[:, 0]) if np.all(v > 0) else "      -")
+        print("   wave %d: %s" % (w, " ".join(row)))
+    raw = buf[:64 * 8 * 8].reshape(64, 8, 8).astype(np.float64)[ok]
+    clk = (raw[:, :, 7] - raw[:, :, 1]) / ((raw[:, :, 3] - raw[:, :, 2]) * 10.0)      # shader cycles per ns over the GEMM
+    print("  shader clock over the GEMM phase: %.3f GHz (median), %.3f .. %.3f" % (np.median(clk), clk.min(), clk.max()))
+    print("  block row (barrier to last wave's last stamp): med %.1f us" % np.median(t[:, :, 4:7].max(axis=(1, 2)) - t0[:, 0]))
 
 
 if __name__ == "__main__":
