@@ -29,6 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+NOMINAL_GHZ = 2.4           # the clock the datasheet peaks are quoted at
 FP64_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix/vector peak (not in the local guide; measured 76.5-77.8)
 FP32_PEAK_TFLOPS = 157.3    # fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 HBM_PEAK_TBS = 8.0          # spec; 6.29 TB/s is what a float4 copy achieves (MI355X_MICROARCH.md)
@@ -308,6 +309,11 @@ def main():
                         "launches (HIP events on the launch stream)",
                 "executed_flops_frac": sum(executed_step_flops(s) for s in mine) / t_steps / 1e12 / peak,
                 "step_launch_us": [round(float(v), 1) for v in np.median(np.array(step_us), axis=0)] if step_us else None}
+        ghz = ctx.shader_clock(0)
+        if ghz > 0:     # the peak is the datasheet's (2.4 GHz); the chip clocks lower under this kernel
+            roof["shader_clock_ghz"] = ghz
+            roof["frac_of_peak_at_that_clock"] = roof["frac"] * NOMINAL_GHZ / ghz
+            roof["executed_flops_frac_at_that_clock"] = roof["executed_flops_frac"] * NOMINAL_GHZ / ghz
         try:    # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
             if cfg == "C" and (P, n) == (256, 2000) and args.eps == 0:
@@ -334,6 +340,10 @@ def main():
         roof_pred = {"bound": "mfma", "kernel": "predict_strip_kernel", "achieved": pf / (pstage["items"] * 1e-3) / 1e12,
                      "peak": peak, "unit": "TFLOP/s", "frac": pf / (pstage["items"] * 1e-3) / 1e12 / peak,
                      "note": "n^2 + 4 n flops per (query, region) pair / device time of the strip kernel"}
+        ghz = ctx.shader_clock(1)
+        if ghz > 0:
+            roof_pred["shader_clock_ghz"] = ghz
+            roof_pred["frac_of_peak_at_that_clock"] = roof_pred["frac"] * NOMINAL_GHZ / ghz
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
             if cfg == "C" and (P, n, nq) == (256, 2000, 1 << 20) and args.eps == 0:

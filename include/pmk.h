@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PMK_VERSION 101
+#define PMK_VERSION 102
 
 /* kernel families = the isbits kernel structs of src/misc/declarations.jl:18-45,65-67,75-111 */
 enum {
@@ -79,6 +79,10 @@ void pmk_ctx_destroy(pmk_ctx *ctx);
  * "solve", "plan", "items", "mix"); enabled by pmk_ctx_enable_timers(ctx, 1) */
 int  pmk_ctx_enable_timers(pmk_ctx *ctx, int on);
 int  pmk_ctx_timer_ms(pmk_ctx *ctx, const char *stage, double *ms);
+/* shader clock (GHz) that workgroup 0 saw over its lifetime in the factorisation step launches of the last fit
+ * (which = 0) or in the last prediction strip kernel (which = 1); 0 if none has run.  The fp64 MFMA peak that the
+ * rooflines are priced against assumes the nominal 2.4 GHz; under these kernels the chip runs slower. */
+int  pmk_ctx_shader_clock(pmk_ctx *ctx, int which, double *ghz);
 
 /* ---- BSP: host, exact (integer outputs are part of the parity contract) --------------- */
 /* setuppartition(X, levels)  src/patchwork/partition.jl:106-129 (+ gethyperplane :86-100,

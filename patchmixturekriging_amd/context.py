@@ -29,6 +29,12 @@ class Context:
         _lib.check(self.L.pmk_ctx_timer_ms(self.h, stage.encode(), C.byref(ms)), "pmk_ctx_timer_ms")
         return ms.value
 
+    def shader_clock(self, which):
+        """GHz seen by workgroup 0 of the last fit's step launches (0) / of the last strip kernel (1); 0.0 if none ran"""
+        g = C.c_double()
+        _lib.check(self.L.pmk_ctx_shader_clock(self.h, int(which), C.byref(g)), "pmk_ctx_shader_clock")
+        return g.value
+
     def close(self):
         if self.h:
             self.L.pmk_ctx_destroy(self.h)

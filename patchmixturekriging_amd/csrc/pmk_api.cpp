@@ -164,6 +164,12 @@ int pmk_ctx_create(int device, pmk_ctx **out)
     }
     c->num_cu = prop.multiProcessorCount;
     c->stream = c->own_stream;
+    if (hipMalloc((void **)&c->d_clk, sizeof(unsigned long long) * 130) != hipSuccess ||
+        hipMemset(c->d_clk, 0, sizeof(unsigned long long) * 130) != hipSuccess) {
+        set_error("pmk_ctx_create: device %d: %s", device, hipGetErrorString(hipGetLastError()));
+        pmk_ctx_destroy(c);
+        return -100;
+    }
     // kernel attributes are per device: set them for this context's device (current after hipSetDevice above)
     if (pmk::f64::set_device_attributes() || pmk::f32::set_device_attributes() || pmk::set_plan_attributes()) {
         pmk_ctx_destroy(c);
@@ -193,7 +199,21 @@ void pmk_ctx_destroy(pmk_ctx *ctx)
     for (auto &t : ctx->tm) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto &e : ctx->panel_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->d_clk) (void)hipFree(ctx->d_clk);
     delete ctx;
+}
+
+int pmk_ctx_shader_clock(pmk_ctx *ctx, int which, double *ghz)
+{
+    if (!ctx || !ghz || which < 0 || which > 1) { set_error("pmk_ctx_shader_clock: bad argument"); return -1; }
+    PMK_HIP(hipSetDevice(ctx->device));
+    unsigned long long h[130];
+    PMK_HIP(hipMemcpyAsync(h, ctx->d_clk, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PMK_HIP(hipStreamSynchronize(ctx->stream));
+    double cyc = 0, ticks = 0;
+    for (int i = which ? 64 : 0; i < (which ? 65 : 64); ++i) { cyc += (double)h[2 * i]; ticks += (double)h[2 * i + 1]; }
+    *ghz = ticks > 0 ? cyc / (ticks * 10.0) : 0.0;          // ticks of 10 ns
+    return 0;
 }
 
 int pmk_ctx_enable_timers(pmk_ctx *ctx, int on)

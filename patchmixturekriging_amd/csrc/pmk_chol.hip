@@ -414,10 +414,15 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
                                                            int launch, int max_nt, real *__restrict__ A,
                                                            real *__restrict__ ninv, const real *__restrict__ y,
                                                            real *__restrict__ z, int32_t *__restrict__ info,
-                                                           const real2_t *__restrict__ partial, int nsplit)
+                                                           const real2_t *__restrict__ partial, int nsplit,
+                                                           unsigned long long *__restrict__ clk)
 {
     __shared__ real lds[TRI_LDS_DOUBLES];
     int slot, bx;
+    // shader-clock probe (workgroup 0 is a critical one: it lives through more than half of the launch)
+    const bool probe = clk && blockIdx.x == 0 && threadIdx.x == 0 && launch < 64;
+    unsigned long long c0 = 0, r0 = 0;
+    if (probe) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     if (SPLIT) {
         // few patches: their block rows are dealt over ALL XCDs (one XCD per patch would leave most of the chip idle);
         // critical workgroups first
@@ -462,6 +467,10 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
     lookahead_potrf<SPLIT>(pd, S, ninv + pd.ioff, y + pd.yoff, z + pd.yoff, info + pid, k, lds,
                            SPLIT ? partial + (((int64_t)slot * (G + 1) + G) * nsplit) * PARTIAL_TILE : nullptr, nsplit);
     PMK_STAMP(5);
+    if (probe) {
+        clk[2 * launch] = __builtin_amdgcn_s_memtime() - c0;
+        clk[2 * launch + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -790,6 +799,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
                   "prefetch depth must divide TILE/4");
     if (p0 != 0 || np != m->P) { set_error("launch_cholesky: sub-batches are not supported"); return -2; }
     PMK_HIP(hipMemsetAsync(m->d_info, 0, sizeof(int32_t) * (size_t)np, s));
+    PMK_HIP(hipMemsetAsync(m->ctx->d_clk, 0, sizeof(unsigned long long) * 128, s));      // shader-clock probe of the step launches
     pmk_ctx *c = m->ctx;
     c->panel_n = 0;
     const bool fine = c->timers >= 2;
@@ -837,11 +847,11 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
                                (real2_t *)m->d_partial);
             hipLaunchKernelGGL(chol_step_kernel<1>, dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
                                m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,
-                               (const real2_t *)m->d_partial, nsplit);
+                               (const real2_t *)m->d_partial, nsplit, m->ctx->d_clk);
         } else {
             hipLaunchKernelGGL(chol_step_kernel<0>, dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
                                m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,
-                               (const real2_t *)nullptr, 1);
+                               (const real2_t *)nullptr, 1, m->ctx->d_clk);
         }
         if (int rc = ev_end(l)) return rc;
     }

@@ -69,7 +69,10 @@ struct WaveTile {
 // loads it had issued a few instructions earlier (a wave alone on its SIMD ran at 73 % of the MFMA rate instead of
 // 90 %; tools/gemm_probe.hip).  Each I slot is refilled right behind the MFMAs that consumed it, so the loads of a
 // k-step are spread over its 16 MFMAs instead of queueing behind the last one.
-template <int NPI, int NPJ, int PFI, int PFJ = PFI, int NACT = NPI>
+#ifndef PMK_PEEL_DEFAULT
+#define PMK_PEEL_DEFAULT false
+#endif
+template <int NPI, int NPJ, int PFI, int PFJ = PFI, int NACT = NPI, bool PEEL = PMK_PEEL_DEFAULT>
 __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI,
                                         const real *opJ, int64_t ldJ, int K, int lane)
 {
@@ -95,7 +98,7 @@ __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, 
         qJ += sJ;
         __builtin_amdgcn_sched_barrier(0);
     }
-    for (int k0 = 0; k0 < K; k0 += 4 * PFJ) {
+    auto pass = [&]() {                   // PFJ k-steps
 #pragma unroll
         for (int s = 0; s < PFJ; ++s) {
             const int si = s % PFI;
@@ -122,14 +125,20 @@ __device__ __forceinline__ void gemm_nt(WaveTile<NPI, NPJ> &t, const real *opI, 
             qI += sI;
             qJ += sJ;
         }
-    }
+    };
+    // PEEL: the first pass is peeled off the loop.  Whatever the code in front of the loop still has in flight when it
+    // enters (a spilled accumulator being reloaded, the caller's last loads) is then waited for once, in the peeled
+    // copy; in a rolled loop that wait sits at the loop head and is executed by every pass -- as vmcnt(0), i.e. for
+    // the ring loads as well.  For callers under register pressure (prediction); it costs code size elsewhere.
+    if (PEEL) pass();
+    for (int k0 = PEEL ? 4 * PFJ : 0; k0 < K; k0 += 4 * PFJ) pass();
 }
 
 // The same product with every ring address recomputed from the k index (clamped at the end: no over-read).  Costs a
 // few more address instructions per k-step but keeps no running pointers alive: the prediction kernel, which is out
 // of registers around its GEMM, gets spill reloads in front of the loop with the pointer form (and with them a
 // vmcnt(1) at the loop head); this form compiles there to clean counted waits.
-template <int NPI, int NPJ, int PFI, int PFJ = PFI, int NACT = NPI>
+template <int NPI, int NPJ, int PFI, int PFJ = PFI, int NACT = NPI, bool PEEL = true>
 __device__ __forceinline__ void gemm_nt_indexed(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI,
                                                 const real *opJ, int64_t ldJ, int K, int lane)
 {
@@ -150,7 +159,7 @@ __device__ __forceinline__ void gemm_nt_indexed(WaveTile<NPI, NPJ> &t, const rea
             rb[s][pj] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(bJ + 32 * pj + (int64_t)(4 * s) * ldJ));
         __builtin_amdgcn_sched_barrier(0);
     }
-    for (int k0 = 0; k0 < K; k0 += 4 * PFJ) {
+    auto pass = [&](int k0) {             // PFJ k-steps
 #pragma unroll
         for (int s = 0; s < PFJ; ++s) {
             const int si = s % PFI;
@@ -175,7 +184,9 @@ __device__ __forceinline__ void gemm_nt_indexed(WaveTile<NPI, NPJ> &t, const rea
                 rb[s][pj] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(bJ + 32 * pj + (int64_t)kj * ldJ));
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
+    };
+    if (PEEL) pass(0);                    // see gemm_nt
+    for (int k0 = PEEL ? 4 * PFJ : 0; k0 < K; k0 += 4 * PFJ) pass(k0);
 }
 
 // In-register triangular solve of a 128-row tile, by block forward substitution over its four

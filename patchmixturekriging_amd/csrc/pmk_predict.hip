@@ -81,7 +81,11 @@ __device__ __forceinline__ void strip_block_row(WaveTile<4, 1> &acc, const real 
     if (i > 0) {
         // order this wave's earlier strip stores before its loads of them
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#ifdef PMK_PRED_POINTER
+        gemm_nt<4, 1, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
+#else
         gemm_nt_indexed<4, 1, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
+#endif
     }
 #ifdef PMK_TRACE
     if (traced && i == PMK_TRACE_ROW && lane == 0 && blockIdx.x < 64) {
@@ -159,9 +163,13 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
                                                                const double *__restrict__ xq, real *__restrict__ strips,
                                                                int64_t strip_stride, pmk_kernel_desc th,
                                                                uint32_t *__restrict__ sync_cnt, int round_base, double min_v,
-                                                               double *__restrict__ u_out, double *__restrict__ v_out)
+                                                               double *__restrict__ u_out, double *__restrict__ v_out,
+                                                               unsigned long long *__restrict__ clk)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // shader-clock probe: cycles and 10 ns ticks of workgroup 0's lifetime (pmk_ctx_shader_clock)
+    unsigned long long c0 = 0, r0 = 0;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     real *V = strips + (int64_t)blockIdx.x * strip_stride + 32 * wave;   // this wave's 32 columns, ld = TQ
     constexpr int PTS = (MAX_D + 1) * TILE;
     __shared__ real pts[3 * PTS];             // training points (SoA) and weights of three consecutive block rows
@@ -328,6 +336,10 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
         // the next task reuses the strip: order its first stores after this task's last loads
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[128] = __builtin_amdgcn_s_memtime() - c0;
+        clk[129] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 #if defined(PMK_TRACE) && !defined(PMK_REAL_F32)
@@ -446,11 +458,11 @@ int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s)
         if (s34)                                                                                                       \
             hipLaunchKernelGGL((predict_strip_kernel<DD, PMK_SPLINE34>), dim3((unsigned)q->strip_grid), dim3(PRED_THREADS), 0, s, \
                                m->d_desc, (real *)m->d_x, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
-                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->min_v, q->d_u, q->d_v);  \
+                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->min_v, q->d_u, q->d_v, m->ctx->d_clk);  \
         else                                                                                                           \
             hipLaunchKernelGGL((predict_strip_kernel<DD, 0>), dim3((unsigned)q->strip_grid), dim3(PRED_THREADS), 0, s,  \
                                m->d_desc, (real *)m->d_x, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
-                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->min_v, q->d_u, q->d_v);  \
+                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->min_v, q->d_u, q->d_v, m->ctx->d_clk);  \
         break;
         PMK_CASE(1) PMK_CASE(2) PMK_CASE(3) PMK_CASE(4)
 #undef PMK_CASE
