@@ -16,7 +16,7 @@ tools/pmc_passes.sh "$out/pmc" --steps 1 --warmup 1 --no-cpu
 cat "$out/pmc/commands.txt" >> "$out/commands.txt"
 echo "== bench lines" | tee -a "$out/commands.txt"
 python3 bench.py > "$out/bench_C.json" 2> "$out/bench_C.log"
-python3 bench.py --eps 0.044 --no-cpu > "$out/ragged_bench.json" 2> "$out/ragged.log"
+python3 bench.py --n 1616 --eps 0.044 --no-cpu > "$out/ragged_bench.json" 2> "$out/ragged.log"
 python3 bench.py --config E --no-cpu --steps 3 --warmup 1 > "$out/config_E_fp32_bench.json" 2> "$out/E.log"
 python3 bench.py --config D --patches 1024 --nq 4194304 --no-cpu --steps 3 --warmup 1 > "$out/config_D_one_gpu_bench.json" 2> "$out/D.log"
 tail -c 600 "$out/bench_C.json"
