@@ -5,6 +5,7 @@ Tolerances (fp64): integer outputs exact; K entries <= 4
 c by residual |Uc - y| / (|U||c| + |y|) <= 1e-13; Yq within 1e-7 max(1,|Yq|);
 Vq within 1e-9 + 1e-5 Vq.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -426,6 +427,26 @@ def test_config_C_full_size_properties():
         worst_y = max(worst_y, abs(Yq[j] - yj) / max(1, abs(yj)))
         worst_v = max(worst_v, abs(Vq[j] - vj) / (1e-9 + 1e-5 * vj))
     assert worst_y <= 1e-7 and worst_v <= 1.0, (worst_y, worst_v)
+
+
+def test_shader_clock_probe_reports_a_plausible_clock():
+    # pmk_ctx_shader_clock: workgroup 0 of the step launches / of the strip kernel stamps shader cycles and 100 MHz ticks
+    rng = np.random.default_rng(5)
+    Xs = [rng.uniform(-3, 3, (700, 2)) for _ in range(6)]
+    ys = [np.sin(x[:, 0]) for x in Xs]
+    th = pmk.Spline34KernelType(0.3)
+    model, cs, info = pmk.fit_patches(Xs, ys, th, 1e-4)
+    assert np.all(info == 0)
+    ghz = model.ctx.shader_clock(0)
+    assert 0.5 < ghz < 3.0, ghz
+    mu, var = np.empty(300), np.empty(300)
+    Xq = np.ascontiguousarray(rng.uniform(-3, 3, (300, 2)))
+    d = th.desc()
+    dp = C.POINTER(C.c_double)
+    rc = model.ctx.L.pmk_model_queryinner_ex(model.h, 0, C.byref(d), 300, Xq.ctypes.data_as(dp), 1e-12, mu.ctypes.data_as(dp),
+                                             var.ctypes.data_as(dp))
+    assert rc == 0
+    assert 0.5 < model.ctx.shader_clock(1) < 3.0
 
 
 @pytest.mark.timeout(900)
