@@ -34,8 +34,16 @@ constexpr int PF_PRED = PMK_PFI_PRED;       // I-operand (factor, from L2) prefe
 #define PMK_PFJ 4
 #endif
 constexpr int PFJ_PRED = PMK_PFJ;   // J-operand (the wave's own strip columns, HBM) prefetch depth
-constexpr int PRED_WAVES = TQ / 32;
+// column pairs (of 32) per wave: 1 = eight waves of 128 x 32 tiles, two per SIMD (256 registers each); 2 = four waves of
+// 128 x 64 tiles, ONE per SIMD with all 512 registers (accumulators in the AGPR half)
+#ifndef PMK_PRED_NPJ
+#define PMK_PRED_NPJ 1
+#endif
+constexpr int NPJW = PMK_PRED_NPJ;
+constexpr int WCOLS = 32 * NPJW;            // query columns of a wave
+constexpr int PRED_WAVES = TQ / WCOLS;
 constexpr int PRED_THREADS = 64 * PRED_WAVES;
+typedef real kvec_t __attribute__((ext_vector_type(2 * NPJW)));      // the kernel values of a lane's columns for one row
 #ifndef PMK_SYNC_TICKS
 #define PMK_SYNC_TICKS 4000         // lock-step rendezvous: give up after 40 us (s_memrealtime ticks of 10 ns)
 #endif
@@ -75,16 +83,16 @@ struct StripTask {
 
 // one block row of the strip: acc = Kq_i (in) -> -V_i (out)
 template <int NACT>
-__device__ __forceinline__ void strip_block_row(WaveTile<4, 1> &acc, const real *Li, int64_t ld, const real *V, int i,
+__device__ __forceinline__ void strip_block_row(WaveTile<4, NPJW> &acc, const real *Li, int64_t ld, const real *V, int i,
                                                 const real *Lii, const real *ninv_i, int lane, bool traced = false)
 {
     if (i > 0) {
         // order this wave's earlier strip stores before its loads of them
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #ifdef PMK_PRED_POINTER
-        gemm_nt<4, 1, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
+        gemm_nt<4, NPJW, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
 #else
-        gemm_nt_indexed<4, 1, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
+        gemm_nt_indexed<4, NPJW, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
 #endif
     }
 #ifdef PMK_TRACE
@@ -95,7 +103,7 @@ __device__ __forceinline__ void strip_block_row(WaveTile<4, 1> &acc, const real 
 #endif
     // the TRSM operands come straight from the factor (prefetched block by block into registers): no LDS copy, no
     // barrier around staging one
-    tri_solve_global<1>(acc, Lii, ld, ninv_i, lane);
+    tri_solve_global<NPJW>(acc, Lii, ld, ninv_i, lane);
 }
 
 // Kq tile of one block row (query is the first kernel argument, mixtureGP.jl:304) into the wave's accumulator, 32 rows
@@ -103,16 +111,17 @@ __device__ __forceinline__ void strip_block_row(WaveTile<4, 1> &acc, const real 
 // of a tile and the accumulator they fill were allocated hundreds of spilled registers (scratch traffic was a quarter
 // of this kernel's HBM bytes) and 3 k instructions of code per block row.  Adds the tile's share of the mean.
 template <int D, int FAM>
-__device__ __forceinline__ void eval_tile(WaveTile<4, 1> &acc, const real *pt, real2_t *mine, real *pk, const pmk_kernel_desc &th,
+__device__ __forceinline__ void eval_tile(WaveTile<4, NPJW> &acc, const real *pt, kvec_t *mine, real *pk, const pmk_kernel_desc &th,
                                           int row0, int n, int lane)
 {
-    // the lane's two query points and running means live in its LDS park between block rows (see the kernel)
-    real q[2][D], mu[2];
+    // the lane's 2 NPJW query points and running means live in its LDS park between block rows (see the kernel)
+    constexpr int NC = 2 * NPJW;
+    real q[NC][D], mu[NC];
 #pragma unroll
-    for (int ej = 0; ej < 2; ++ej) {
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) q[ej][d] = pk[(ej * D + d) * PRED_THREADS];
-        mu[ej] = pk[(2 * D + ej) * PRED_THREADS];
+        for (int d = 0; d < D; ++d) q[c][d] = pk[(c * D + d) * PRED_THREADS];
+        mu[c] = pk[(NC * D + c) * PRED_THREADS];
     }
 #pragma unroll
     for (int pi = 0; pi < 4; ++pi) {
@@ -126,22 +135,23 @@ __device__ __forceinline__ void eval_tile(WaveTile<4, 1> &acc, const real *pt, r
             // padding rows carry coordinates of 1e300 (pack_soa): a compactly supported profile is
             // exactly 0 there, so the Spline34 instantiation needs no bounds test
             const bool inside = (FAM == PMK_SPLINE34) || row0 + r < n;
-            real2_t kv;
-            kv[0] = inside ? kern_eval<D, FAM, real>(th, q[0], xr) : (real)0;
-            kv[1] = inside ? kern_eval<D, FAM, real>(th, q[1], xr) : (real)0;
-            mu[0] += kv[0] * cw;
-            mu[1] += kv[1] * cw;
+            kvec_t kv;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                kv[c] = inside ? kern_eval<D, FAM, real>(th, q[c], xr) : (real)0;
+                mu[c] += kv[c] * cw;
+            }
             mine[sl * 64] = kv;
         }
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) {
-            const real2_t kv = mine[sl * 64];
-            acc.f[2 * pi + (sl & 1)][0][sl >> 1] = kv[0];
-            acc.f[2 * pi + (sl & 1)][1][sl >> 1] = kv[1];
+            const kvec_t kv = mine[sl * 64];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc.f[2 * pi + (sl & 1)][c][sl >> 1] = kv[c];
         }
     }
-    pk[(2 * D + 0) * PRED_THREADS] = mu[0];
-    pk[(2 * D + 1) * PRED_THREADS] = mu[1];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) pk[(NC * D + c) * PRED_THREADS] = mu[c];
 }
 
 // Schedule of a strip.  One barrier per block row.  Everything that is not an MFMA is kept off the critical path:
@@ -154,7 +164,7 @@ __device__ __forceinline__ void eval_tile(WaveTile<4, 1> &acc, const real *pt, r
 //  * the lock-step rendezvous with the other strips of the region is split-phase: thread 0 (wave 0, an early
 //    finisher) arrives for the next block row and spins, bounded, before the barrier.
 template <int D, int FAM>
-__global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const PatchDesc *__restrict__ descs,
+__global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip_kernel(const PatchDesc *__restrict__ descs,
                                                                const real *__restrict__ x, const real *__restrict__ A,
                                                                const real *__restrict__ inv, const real *__restrict__ cvec,
                                                                const StripTask *__restrict__ tasks, int ntasks,
@@ -170,15 +180,16 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
     // shader-clock probe: cycles and 10 ns ticks of workgroup 0's lifetime (pmk_ctx_shader_clock)
     unsigned long long c0 = 0, r0 = 0;
     if (clk && blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-    real *V = strips + (int64_t)blockIdx.x * strip_stride + 32 * wave;   // this wave's 32 columns, ld = TQ
+    real *V = strips + (int64_t)blockIdx.x * strip_stride + WCOLS * wave;   // this wave's columns, ld = TQ
     constexpr int PTS = (MAX_D + 1) * TILE;
     __shared__ real pts[3 * PTS];             // training points (SoA) and weights of three consecutive block rows
-    __shared__ real priv[PRED_WAVES * 8 * 64 * 2];   // lane-private staging of the kernel evaluations (8 slots a lane)
-    real2_t *mine = reinterpret_cast<real2_t *>(priv) + (wave * 8) * 64 + lane;
+    __shared__ real priv[PRED_WAVES * 8 * 64 * 2 * NPJW];   // lane-private staging of the kernel evaluations (8 slots a lane)
+    kvec_t *mine = reinterpret_cast<kvec_t *>(priv) + (wave * 8) * 64 + lane;
     // Per-thread values that are only needed between the MFMA phases (the two query points, the running means and
     // squared norms) are PARKED in LDS: around its GEMM the kernel has no register to spare (128 accumulator + 80 ring
     // registers of 256), and what the compiler spills instead goes to scratch memory, in the middle of the hot loops.
-    __shared__ real park[(2 * MAX_D + 4) * PRED_THREADS];
+    constexpr int NC = 2 * NPJW;                   // query columns of a lane
+    __shared__ real park[(NC * MAX_D + 2 * NC) * PRED_THREADS];
     real *pk = park + threadIdx.x;      // slot k of this thread: pk[k * PRED_THREADS]
 
     // XCD-aware task order: the workgroups of one XCD take consecutive tasks (= strips of the same
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
         }
         const int task = base + xcd_remap(blockIdx.x, nin);
         const StripTask tk = tasks[task];
-        const bool active = 32 * wave < tk.count;     // wave-uniform
+        const bool active = WCOLS * wave < tk.count;     // wave-uniform
         const PatchDesc pd = descs[tk.region];
         const real *S = A + pd.aoff;
         const real *xs = x + pd.xoff;
@@ -240,16 +251,16 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
             dst[D * TILE + t] = cr[row];
         };
 
-        // the lane's 2 query columns: 2 (lane & 15) + ej of the wave's 32 (padding columns repeat a valid item)
+        // the lane's query columns: 32 pj + 2 (lane & 15) + ej of the wave's WCOLS (padding columns repeat a valid item)
 #pragma unroll
-        for (int ej = 0; ej < 2; ++ej) {
-            const int col = 32 * wave + 2 * (lane & 15) + ej;
+        for (int c = 0; c < NC; ++c) {
+            const int col = WCOLS * wave + 32 * (c >> 1) + 2 * (lane & 15) + (c & 1);
             const int64_t p = tk.first + (col < tk.count ? col : 0);
             const int64_t qi = item_query[sorted_item[p]];
 #pragma unroll
-            for (int d = 0; d < D; ++d) pk[(ej * D + d) * PRED_THREADS] = (real)xq[qi * D + d];
-            pk[(2 * D + ej) * PRED_THREADS] = (real)0;           // mean
-            pk[(2 * D + 2 + ej) * PRED_THREADS] = (real)0;       // |V|^2
+            for (int d = 0; d < D; ++d) pk[(c * D + d) * PRED_THREADS] = (real)xq[qi * D + d];
+            pk[(NC * D + c) * PRED_THREADS] = (real)0;            // mean
+            pk[(NC * D + NC + c) * PRED_THREADS] = (real)0;       // |V|^2
         }
         // rows of the last block row that are not identity padding, in 32-row pairs (n = 2000: 3 of 4)
         const int last_pairs = (pd.n - (pd.nt - 1) * TILE + 31) >> 5;
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
         __syncthreads();                              // every wave is done with the previous task's points
         if (threadIdx.x < 2 * TILE && (int)(threadIdx.x >> 7) < pd.nt) stage_points(threadIdx.x >> 7, threadIdx.x & (TILE - 1));
         if (threadIdx.x == 0 && tk.group >= 0) rendezvous(0);
-        WaveTile<4, 1> acc;
+        WaveTile<4, NPJW> acc;
         bool have = false;                            // acc already holds this block row's kernel tile
         for (int i = 0; i < pd.nt; ++i) {
             __syncthreads();                          // block row i - 1 is complete in every wave; points of row i, i + 1 visible
@@ -281,15 +292,17 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
                 else strip_block_row<4>(acc, Li, ld, V, i, Lii, ninv_i, lane, PMK_TRACED);
                 PMK_PSTAMP(4);
                 {
-                    real vs[2] = {pk[(2 * D + 2) * PRED_THREADS], pk[(2 * D + 3) * PRED_THREADS]};
+                    real vs[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) vs[c] = pk[(NC * D + NC + c) * PRED_THREADS];
 #pragma unroll
                     for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
                         for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-                            for (int ej = 0; ej < 2; ++ej) vs[ej] += acc.f[fi][ej][qq] * acc.f[fi][ej][qq];
-                    pk[(2 * D + 2) * PRED_THREADS] = vs[0];
-                    pk[(2 * D + 3) * PRED_THREADS] = vs[1];
+                            for (int c = 0; c < NC; ++c) vs[c] += acc.f[fi][c][qq] * acc.f[fi][c][qq];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) pk[(NC * D + NC + c) * PRED_THREADS] = vs[c];
                 }
                 have = false;
                 if (i + 1 < pd.nt) {
@@ -300,13 +313,16 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
 #pragma unroll
                         for (int qq = 0; qq < 4; ++qq) {
                             const int row = i * TILE + srow + (tile_i(fi, 0, qq) - tile_i(0, 0, 0));
-                            real2_t o;
-                            o[0] = acc.f[fi][0][qq];
-                            o[1] = acc.f[fi][1][qq];
-                            __builtin_nontemporal_store(o, reinterpret_cast<real2_t *>(V + (int64_t)row * TQ + 2 * (lane & 15)));
+#pragma unroll
+                            for (int pj = 0; pj < NPJW; ++pj) {
+                                real2_t o;
+                                o[0] = acc.f[fi][2 * pj][qq];
+                                o[1] = acc.f[fi][2 * pj + 1][qq];
+                                __builtin_nontemporal_store(o, reinterpret_cast<real2_t *>(V + (int64_t)row * TQ + 32 * pj + 2 * (lane & 15)));
+                            }
                         }
                     PMK_PSTAMP(5);
-                    if (wave < PRED_WAVES / 2) {      // the older wave of its SIMD: next tile now, in its idle time
+                    if (NPJW == 1 && wave < PRED_WAVES / 2) {      // the older wave of its SIMD: next tile now, in its idle time
                         eval_tile<D, FAM>(acc, pts + ((i + 1) % 3) * PTS, mine, pk, th, (i + 1) * TILE, pd.n, lane);
                         have = true;
                     }
@@ -317,15 +333,15 @@ __global__ __launch_bounds__(PRED_THREADS, 2) void predict_strip_kernel(const Pa
         }
         // ---- reduce over the four lane groups that share a column, then write (u, v)
 #pragma unroll
-        for (int ej = 0; ej < 2 && active; ++ej) {
-            real a = pk[(2 * D + ej) * PRED_THREADS], b = pk[(2 * D + 2 + ej) * PRED_THREADS];
+        for (int c = 0; c < NC && active; ++c) {
+            real a = pk[(NC * D + c) * PRED_THREADS], b = pk[(NC * D + NC + c) * PRED_THREADS];
             a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
             a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-            const int col = 32 * wave + 2 * (lane & 15) + ej;
+            const int col = WCOLS * wave + 32 * (c >> 1) + 2 * (lane & 15) + (c & 1);
             if ((lane >> 4) == 0 && col < tk.count) {
                 real qe[D];
 #pragma unroll
-                for (int d = 0; d < D; ++d) qe[d] = pk[(ej * D + d) * PRED_THREADS];
+                for (int d = 0; d < D; ++d) qe[d] = pk[(c * D + d) * PRED_THREADS];
                 const real kself = kern_eval<D, FAM, real>(th, qe, qe);
                 double var = (double)kself - (double)b;               // mixtureGP.jl:312
                 var = var < min_v ? min_v : var;                     // clamp(..., min_v, Inf)

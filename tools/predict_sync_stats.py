@@ -45,18 +45,20 @@ def main():
     buf = np.zeros(512 * 40, dtype=np.uint64)
     L.pmk_trace_sync_stats(buf.ctypes.data_as(C.c_void_p), 2)
     t = buf[:64 * 8 * 8].reshape(64, 8, 8).astype(np.float64) / 100.0          # [wg][wave][stamp] in us
+    nw = 8 if t[:, 4:, 0].max() > 0 else 4                     # 8 waves of 32 columns or 4 waves of 64 (PMK_PRED_NPJ = 2)
+    t = t[:, :nw]
     ok = (t[:, :, 4].min(axis=1) > 0) & (t[:, :, 0].min(axis=1) > 0)
     t = t[ok]
     print("timeline of one block row (traced row / round are compile-time), %d workgroups; us after the barrier, median over" % len(t))
     print("workgroups; stamps: 0 barrier passed, 2 kernel tile ready, 3 GEMM done, 4 TRSM done, 5 V stored, 6 next tile pre-evaluated")
     t0 = t[:, :, 0].min(axis=1)[:, None]
-    for w in range(8):
+    for w in range(nw):
         row = []
         for k in (0, 2, 3, 4, 5, 6):
             v = t[:, w, k]
             row.append("%7.1f" % np.median(v - t0[:, 0]) if np.all(v > 0) else "      -")
         print("   wave %d: %s" % (w, " ".join(row)))
-    raw = buf[:64 * 8 * 8].reshape(64, 8, 8).astype(np.float64)[ok]
+    raw = buf[:64 * 8 * 8].reshape(64, 8, 8).astype(np.float64)[:, :nw][ok]
     clk = (raw[:, :, 7] - raw[:, :, 1]) / ((raw[:, :, 3] - raw[:, :, 2]) * 10.0)      # shader cycles per ns over the GEMM
     print("  shader clock over the GEMM phase: %.3f GHz (median), %.3f .. %.3f" % (np.median(clk), clk.min(), clk.max()))
     print("  block row (barrier to last wave's last stamp): med %.1f us" % np.median(t[:, :, 4:7].max(axis=(1, 2)) - t0[:, 0]))
