@@ -73,6 +73,11 @@ const char *pmk_last_error(void);
 int  pmk_ctx_create(int device, pmk_ctx **out);
 /* launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL -> context's own */
 int  pmk_ctx_set_stream(pmk_ctx *ctx, void *hip_stream);
+/* on = 1: pmk_model_fit builds the kernel matrix block column by block column on a low-priority side stream while the
+ * factorisation's launches run (results are bit-identical either way).  Default 0 = build it first, on the context's
+ * stream: on MI355X the overlap measured 0.3 ms slower per 256 x 2000 fit (the step launches leave no room).  Never
+ * pipelined while stage timers are on or on the split path.  Environment: PMK_PIPELINE_K1=1. */
+int  pmk_ctx_set_pipeline(pmk_ctx *ctx, int on);
 int  pmk_ctx_synchronize(pmk_ctx *ctx);
 void pmk_ctx_destroy(pmk_ctx *ctx);
 /* elapsed ms of the most recent staged call's named stage ("kernel_matrix", "cholesky",

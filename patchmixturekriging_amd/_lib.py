@@ -54,6 +54,7 @@ SIGNATURES = {
     "pmk_ctx_synchronize": (C.c_int, [_vp]),
     "pmk_ctx_destroy": (None, [_vp]),
     "pmk_ctx_enable_timers": (C.c_int, [_vp, C.c_int]),
+    "pmk_ctx_set_pipeline": (C.c_int, [_vp, C.c_int]),
     "pmk_ctx_shader_clock": (C.c_int, [_vp, C.c_int, _dp]),
     "pmk_ctx_timer_ms": (C.c_int, [_vp, C.c_char_p, _dp]),
     "pmk_bsp_build": (C.c_int, [C.c_int, C.c_int64, _dp, C.c_int, C.c_int, C.c_int, _vpp]),

@@ -29,6 +29,10 @@ class Context:
         _lib.check(self.L.pmk_ctx_timer_ms(self.h, stage.encode(), C.byref(ms)), "pmk_ctx_timer_ms")
         return ms.value
 
+    def set_pipeline(self, on):
+        """pipelined kernel-matrix build of fit (default off: measured slower on MI355X)"""
+        _lib.check(self.L.pmk_ctx_set_pipeline(self.h, 1 if on else 0), "pmk_ctx_set_pipeline")
+
     def shader_clock(self, which):
         """GHz seen by workgroup 0 of the last fit's step launches (0) / of the last strip kernel (1); 0.0 if none ran"""
         g = C.c_double()

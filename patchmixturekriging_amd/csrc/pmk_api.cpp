@@ -156,14 +156,21 @@ int pmk_ctx_create(int device, pmk_ctx **out)
     if (!c) { set_error("out of memory"); return -100; }
     c->device = device;
     hipDeviceProp_t prop;
+    // the context's own stream gets the highest priority, the side stream of the pipelined kernel-matrix build the
+    // lowest: its workgroups then only take what the factorisation's launches leave free
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipGetDeviceProperties(&prop, device) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fit_begin, hipEventDisableTiming) != hipSuccess) {
         set_error("pmk_ctx_create: device %d: %s", device, hipGetErrorString(hipGetLastError()));
         delete c;
         return -100;
     }
     c->num_cu = prop.multiProcessorCount;
     c->stream = c->own_stream;
+    if (const char *e = std::getenv("PMK_PIPELINE_K1")) c->pipeline_k1 = std::atoi(e) != 0;      // A/B switch
     if (hipMalloc((void **)&c->d_clk, sizeof(unsigned long long) * 130) != hipSuccess ||
         hipMemset(c->d_clk, 0, sizeof(unsigned long long) * 130) != hipSuccess) {
         set_error("pmk_ctx_create: device %d: %s", device, hipGetErrorString(hipGetLastError()));
@@ -186,6 +193,13 @@ int pmk_ctx_set_stream(pmk_ctx *ctx, void *hip_stream)
     return 0;
 }
 
+int pmk_ctx_set_pipeline(pmk_ctx *ctx, int on)
+{
+    if (!ctx) { set_error("pmk_ctx_set_pipeline: ctx is NULL"); return -1; }
+    ctx->pipeline_k1 = on != 0;
+    return 0;
+}
+
 int pmk_ctx_synchronize(pmk_ctx *ctx)
 {
     if (!ctx) { set_error("pmk_ctx_synchronize: ctx is NULL"); return -1; }
@@ -199,6 +213,9 @@ void pmk_ctx_destroy(pmk_ctx *ctx)
     for (auto &t : ctx->tm) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto &e : ctx->panel_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->fit_begin) (void)hipEventDestroy(ctx->fit_begin);
+    for (auto &e : ctx->col_ev) (void)hipEventDestroy(e);
     if (ctx->d_clk) (void)hipFree(ctx->d_clk);
     delete ctx;
 }
@@ -591,12 +608,35 @@ int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)
     m->sigma2 = sigma2;
     int rc;
     c->tic("fit");
-    c->tic("kernel_matrix");
-    if ((rc = PMK_BY_DTYPE(m, launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P)))) return rc;
-    c->toc("kernel_matrix");
-    c->tic("cholesky");
-    if ((rc = PMK_BY_DTYPE(m, launch_cholesky(m, c->stream, 0, m->P)))) return rc;
-    c->toc("cholesky");
+    // Pipelined kernel-matrix build (OFF by default: measured 0.3 ms SLOWER at config C, profiles/r02_fit_experiments.txt;
+    // pmk_ctx_set_pipeline turns it on; never while stage timers are on or on the split path): K1 is HBM-write bound
+    // and the step launches MFMA bound, so K1 goes block column by block column onto a low-priority side stream and
+    // launch l of the factorisation waits for the columns it reads (stages <= l + 1).  The side stream starts behind
+    // everything already queued on the context's stream (the slabs still hold the previous factor, which earlier
+    // predictions may be reading).
+    const bool pipelined = c->pipeline_k1 && !c->timers && !m->split_mode && m->max_nt >= 3 && c->side_stream;
+    if (pipelined) {
+        const int n_ev = m->max_nt;
+        while ((int)c->col_ev.size() < n_ev) {
+            hipEvent_t e;
+            PMK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->col_ev.push_back(e);
+        }
+        PMK_HIP(hipEventRecord(c->fit_begin, c->stream));
+        PMK_HIP(hipStreamWaitEvent(c->side_stream, c->fit_begin, 0));
+        for (int st = 0; st < n_ev; ++st) {
+            if ((rc = PMK_BY_DTYPE(m, launch_kernel_matrix_slabs(m, *th, sigma2, c->side_stream, 0, m->P, st)))) return rc;
+            PMK_HIP(hipEventRecord(c->col_ev[(size_t)st], c->side_stream));
+        }
+        if ((rc = PMK_BY_DTYPE(m, launch_cholesky(m, c->stream, 0, m->P, c->col_ev.data(), n_ev)))) return rc;
+    } else {
+        c->tic("kernel_matrix");
+        if ((rc = PMK_BY_DTYPE(m, launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P, -1)))) return rc;
+        c->toc("kernel_matrix");
+        c->tic("cholesky");
+        if ((rc = PMK_BY_DTYPE(m, launch_cholesky(m, c->stream, 0, m->P, nullptr, 0)))) return rc;
+        c->toc("cholesky");
+    }
     c->tic("solve");
     if ((rc = PMK_BY_DTYPE(m, launch_backsolve(m, c->stream, 0, m->P)))) return rc;
     c->toc("solve");

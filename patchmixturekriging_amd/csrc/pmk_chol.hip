@@ -792,7 +792,9 @@ static int reserve_split(pmk_model *m, size_t partial_bytes, size_t solve_bytes)
     return 0;
 }
 
-int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
+// col_ev (may be null): event s of the pipelined kernel-matrix build = "stage s is in the slabs"; launch l reads block
+// columns that stages <= l + 1 produced (pmk_kmat.hip), the first kernel reads stage 0
+int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const hipEvent_t *col_ev, int n_ev)
 {
     // gemm_nt consumes K in groups of 4*PF k-indices; K is always a multiple of TILE here
     static_assert(TILE % (4 * PF_DIAG) == 0 && TILE % (4 * PF_CHOL) == 0 && TILE % (4 * PFJ_CHOL) == 0,
@@ -822,6 +824,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
         return 0;
     };
     const int l0 = 0;
+    if (col_ev && n_ev > 0) PMK_HIP(hipStreamWaitEvent(s, col_ev[0], 0));
     hipLaunchKernelGGL(chol_first_kernel, dim3((unsigned)np), dim3(256), 0, s, m->d_desc, (real *)m->d_a, (real *)m->d_inv,
                        (const real *)m->d_y, (real *)m->d_z, m->d_info);
     for (int l = l0; l + 1 < m->max_nt; ++l) {
@@ -829,6 +832,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np)
         // nt_p >= max_nt - l + l0.  Those patches are a prefix of `order` (sorted by nt, largest first).
         const int nactive = m->active_prefix[(size_t)std::min(m->max_nt + 1, m->max_nt - l + l0)];
         const int G = m->max_nt - l - 1;                   // block rows below the diagonal, the same for every active patch
+        if (col_ev && l + 1 < n_ev) PMK_HIP(hipStreamWaitEvent(s, col_ev[l + 1], 0));
         if (nactive == 0) continue;
         if (int rc = ev_begin(l)) return rc;
         // split path: K chunks so that ONE patch's tiles x chunks would fill the chip (a function of the step alone, not

@@ -71,6 +71,12 @@ struct pmk_ctx {
     // (shader cycles, 100 MHz ticks) of its own lifetime here: [2 l], [2 l + 1] for step launch l < 64, [128], [129]
     // for the strip kernel.  The roofline's peak assumes the nominal clock; this says what the kernel actually got.
     unsigned long long *d_clk = nullptr;
+    // pipelined kernel-matrix build: K1 runs block column by block column on a low-priority side stream while the
+    // factorisation's step launches (which wait on the per-column events) keep the matrix pipes busy
+    hipStream_t side_stream = nullptr;
+    hipEvent_t fit_begin = nullptr;
+    std::vector<hipEvent_t> col_ev;
+    int pipeline_k1 = 0;            // pmk_ctx_set_pipeline(ctx, 1) / PMK_PIPELINE_K1=1 turns it on
     void tic(const char *name);
     void toc(const char *name);
 };
@@ -152,8 +158,8 @@ namespace pmk {
 #define PMK_DECLARE_REAL_LAUNCHERS(NS)                                                                              \
     namespace NS {                                                                                                   \
     int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s,      \
-                                   int64_t p0, int64_t np);                                                          \
-    int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);                                        \
+                                   int64_t p0, int64_t np, int stage);                                               \
+    int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const hipEvent_t *col_ev, int n_ev);    \
     int launch_backsolve(pmk_model *m, hipStream_t s, int64_t p0, int64_t np);                                       \
     int launch_ninv_from_slabs(pmk_model *m, hipStream_t s);                                                         \
     int set_device_attributes();                                                                                     \

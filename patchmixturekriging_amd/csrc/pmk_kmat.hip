@@ -13,20 +13,34 @@ namespace PMK_NS {
 // 16-thread row group stores 512 contiguous bytes per column.  Padding rows/columns (index >= n) are
 // written as identity so the padded factorisation stays positive definite.
 // =============================================================================================
+// stage < 0: the whole lower triangle of every patch (grid.x = its 64 x 64 tiles).  stage >= 0: ONE 128-wide block
+// column per patch -- the one the factorisation needs next: block column 0 of every patch at stage 0, block column
+// c >= 1 of patch p at stage c + (max_nt - nt_p) (the end-aligned schedule of the step launches, which read block
+// columns <= k + 1 at launch l = k + max_nt - nt_p, i.e. stages <= l + 1); grid.x = 2 * (64-row tiles of the tallest patch).
 template <int D, int FAM>
 __global__ __launch_bounds__(256) void kmat_slab_kernel(const PatchDesc *__restrict__ descs, const real *__restrict__ x,
-                                                        real *__restrict__ A, pmk_kernel_desc th, double sigma2_d)
+                                                        real *__restrict__ A, pmk_kernel_desc th, double sigma2_d, int stage,
+                                                        int max_nt)
 {
     const PatchDesc pd = descs[blockIdx.y];
     const real sigma2 = (real)sigma2_d;
     const int nt64 = pd.ld / 64;
-    const int ntiles = nt64 * (nt64 + 1) / 2;
-    const int t = blockIdx.x;
-    if (t >= ntiles) return;
-    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    const int tj = t - ti * (ti + 1) / 2;
+    int ti, tj;
+    if (stage < 0) {
+        const int ntiles = nt64 * (nt64 + 1) / 2;
+        const int t = blockIdx.x;
+        if (t >= ntiles) return;
+        ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        tj = t - ti * (ti + 1) / 2;
+    } else {
+        const int c = stage == 0 ? 0 : stage - (max_nt - pd.nt);       // block column of this patch at this stage
+        if (c < (stage == 0 ? 0 : 1) || c >= pd.nt) return;
+        tj = 2 * c + (blockIdx.x & 1);
+        ti = tj + (int)(blockIdx.x >> 1);
+        if (ti >= nt64) return;
+    }
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i0 = ti * 64 + 4 * tx, j0 = tj * 64 + 4 * ty;
     const real *xs = x + pd.xoff;
@@ -60,14 +74,15 @@ __global__ __launch_bounds__(256) void kmat_slab_kernel(const PatchDesc *__restr
 }
 
 template <int D>
-static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s, int64_t p0, int64_t np)
+static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s, int64_t p0, int64_t np,
+                         int stage)
 {
     const int nt64 = m->max_nt * (TILE / 64);
-    dim3 grid((unsigned)(nt64 * (nt64 + 1) / 2), (unsigned)np);
+    dim3 grid((unsigned)(stage < 0 ? nt64 * (nt64 + 1) / 2 : 2 * nt64), (unsigned)np);
     if (th.family == PMK_SPLINE34)
-        hipLaunchKernelGGL((kmat_slab_kernel<D, PMK_SPLINE34>), grid, dim3(256), 0, s, m->d_desc + p0, (const real *)m->d_x, (real *)m->d_a, th, sigma2);
+        hipLaunchKernelGGL((kmat_slab_kernel<D, PMK_SPLINE34>), grid, dim3(256), 0, s, m->d_desc + p0, (const real *)m->d_x, (real *)m->d_a, th, sigma2, stage, m->max_nt);
     else
-        hipLaunchKernelGGL((kmat_slab_kernel<D, 0>), grid, dim3(256), 0, s, m->d_desc + p0, (const real *)m->d_x, (real *)m->d_a, th, sigma2);
+        hipLaunchKernelGGL((kmat_slab_kernel<D, 0>), grid, dim3(256), 0, s, m->d_desc + p0, (const real *)m->d_x, (real *)m->d_a, th, sigma2, stage, m->max_nt);
     PMK_HIP(hipGetLastError());
     return 0;
 }
@@ -82,10 +97,10 @@ static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double s
     }
 
 int launch_kernel_matrix_slabs(const pmk_model *m, const pmk_kernel_desc &th, double sigma2, hipStream_t s,
-                               int64_t p0, int64_t np)
+                               int64_t p0, int64_t np, int stage)
 {
     int rc = 0;
-    PMK_DISPATCH_D(m->D, rc = launch_slab_D<DD>(m, th, sigma2, s, p0, np));
+    PMK_DISPATCH_D(m->D, rc = launch_slab_D<DD>(m, th, sigma2, s, p0, np, stage));
     return rc;
 }
 

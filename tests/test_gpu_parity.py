@@ -429,6 +429,30 @@ def test_config_C_full_size_properties():
     assert worst_y <= 1e-7 and worst_v <= 1.0, (worst_y, worst_v)
 
 
+def test_pipelined_kernel_matrix_build_is_bit_identical():
+    # pmk_model_fit builds K block column by block column on a side stream while the step launches run (stages follow
+    # the end-aligned schedule of ragged batches); the factor and the weights must not depend on it
+    rng = np.random.default_rng(77)
+    sizes = [300, 1000, 640, 129, 128, 2000, 2241, 5, 385]
+    Xs = [rng.uniform(-4, 4, (n, 2)) for n in sizes]
+    ys = [np.sin(x[:, 0]) * np.cos(0.5 * x[:, 1]) for x in Xs]
+    th = pmk.Spline34KernelType(1 / 3.0)
+    ctx = pmk.default_context()
+    out = []
+    for on in (False, True, True):
+        ctx.set_pipeline(on)
+        model = pmk.DeviceModel(Xs, ys)
+        model.fit(th, 1e-5)
+        model.fit(th, 1e-5)                     # a second fit over the previous factor (the side stream must wait for it)
+        assert np.all(model.info() == 0)
+        out.append([(model.get(r, M.GET_C), model.get(r, M.GET_L)) for r in range(len(sizes))])
+    ctx.set_pipeline(False)
+    for r in range(len(sizes)):
+        for k in (1, 2):
+            assert np.array_equal(out[0][r][0], out[k][r][0]) and np.array_equal(out[0][r][1], out[k][r][1])
+    _check_fit(model, 6, Xs[6], ys[6], O.kernel(O.SPLINE34, 1 / 3.0), 1e-5)
+
+
 def test_shader_clock_probe_reports_a_plausible_clock():
     # pmk_ctx_shader_clock: workgroup 0 of the step launches / of the strip kernel stamps shader cycles and 100 MHz ticks
     rng = np.random.default_rng(5)
