@@ -84,8 +84,8 @@ void pmk_ctx_destroy(pmk_ctx *ctx);
  * "solve", "plan", "items", "mix"); enabled by pmk_ctx_enable_timers(ctx, 1) */
 int  pmk_ctx_enable_timers(pmk_ctx *ctx, int on);
 int  pmk_ctx_timer_ms(pmk_ctx *ctx, const char *stage, double *ms);
-/* shader clock (GHz) that workgroup 0 saw over its lifetime in the factorisation step launches of the last fit
- * (which = 0) or in the last prediction strip kernel (which = 1); 0 if none has run.  The fp64 MFMA peak that the
+/* shader clock (GHz) that workgroups 0..7 (one per XCD) saw over their lifetime in the factorisation step launches of
+ * the last fit (which = 0) or in the last prediction strip kernel (which = 1), time-weighted mean; 0 if none has run.  The fp64 MFMA peak that the
  * rooflines are priced against assumes the nominal 2.4 GHz; under these kernels the chip runs slower. */
 int  pmk_ctx_shader_clock(pmk_ctx *ctx, int which, double *ghz);
 

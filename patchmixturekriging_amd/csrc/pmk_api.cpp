@@ -171,8 +171,8 @@ int pmk_ctx_create(int device, pmk_ctx **out)
     c->num_cu = prop.multiProcessorCount;
     c->stream = c->own_stream;
     if (const char *e = std::getenv("PMK_PIPELINE_K1")) c->pipeline_k1 = std::atoi(e) != 0;      // A/B switch
-    if (hipMalloc((void **)&c->d_clk, sizeof(unsigned long long) * 130) != hipSuccess ||
-        hipMemset(c->d_clk, 0, sizeof(unsigned long long) * 130) != hipSuccess) {
+    if (hipMalloc((void **)&c->d_clk, sizeof(unsigned long long) * 130 * 8) != hipSuccess ||
+        hipMemset(c->d_clk, 0, sizeof(unsigned long long) * 130 * 8) != hipSuccess) {
         set_error("pmk_ctx_create: device %d: %s", device, hipGetErrorString(hipGetLastError()));
         pmk_ctx_destroy(c);
         return -100;
@@ -224,11 +224,15 @@ int pmk_ctx_shader_clock(pmk_ctx *ctx, int which, double *ghz)
 {
     if (!ctx || !ghz || which < 0 || which > 1) { set_error("pmk_ctx_shader_clock: bad argument"); return -1; }
     PMK_HIP(hipSetDevice(ctx->device));
-    unsigned long long h[130];
+    unsigned long long h[130 * 8];
     PMK_HIP(hipMemcpyAsync(h, ctx->d_clk, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PMK_HIP(hipStreamSynchronize(ctx->stream));
-    double cyc = 0, ticks = 0;
-    for (int i = which ? 64 : 0; i < (which ? 65 : 64); ++i) { cyc += (double)h[2 * i]; ticks += (double)h[2 * i + 1]; }
+    double cyc = 0, ticks = 0;          // time-weighted mean over the launches and the 8 probing workgroups
+    for (int x = 0; x < 8; ++x)
+        for (int i = which ? 64 : 0; i < (which ? 65 : 64); ++i) {
+            cyc += (double)h[130 * x + 2 * i];
+            ticks += (double)h[130 * x + 2 * i + 1];
+        }
     *ghz = ticks > 0 ? cyc / (ticks * 10.0) : 0.0;          // ticks of 10 ns
     return 0;
 }

@@ -419,8 +419,8 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
 {
     __shared__ real lds[TRI_LDS_DOUBLES];
     int slot, bx;
-    // shader-clock probe (workgroup 0 is a critical one: it lives through more than half of the launch)
-    const bool probe = clk && blockIdx.x == 0 && threadIdx.x == 0 && launch < 64;
+    // shader-clock probe (workgroups 0..7 are critical ones, one per XCD: they live through more than half of the launch)
+    const bool probe = clk && blockIdx.x < 8 && threadIdx.x == 0 && launch < 64;
     unsigned long long c0 = 0, r0 = 0;
     if (probe) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     if (SPLIT) {
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
                            SPLIT ? partial + (((int64_t)slot * (G + 1) + G) * nsplit) * PARTIAL_TILE : nullptr, nsplit);
     PMK_STAMP(5);
     if (probe) {
-        clk[2 * launch] = __builtin_amdgcn_s_memtime() - c0;
-        clk[2 * launch + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+        clk[130 * blockIdx.x + 2 * launch] = __builtin_amdgcn_s_memtime() - c0;
+        clk[130 * blockIdx.x + 2 * launch + 1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 }
 
@@ -801,7 +801,8 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
                   "prefetch depth must divide TILE/4");
     if (p0 != 0 || np != m->P) { set_error("launch_cholesky: sub-batches are not supported"); return -2; }
     PMK_HIP(hipMemsetAsync(m->d_info, 0, sizeof(int32_t) * (size_t)np, s));
-    PMK_HIP(hipMemsetAsync(m->ctx->d_clk, 0, sizeof(unsigned long long) * 128, s));      // shader-clock probe of the step launches
+    for (int x = 0; x < 8; ++x)         // shader-clock probe of the step launches (the strip kernel's pair stays)
+        PMK_HIP(hipMemsetAsync(m->ctx->d_clk + 130 * x, 0, sizeof(unsigned long long) * 128, s));
     pmk_ctx *c = m->ctx;
     c->panel_n = 0;
     const bool fine = c->timers >= 2;

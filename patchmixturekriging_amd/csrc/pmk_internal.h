@@ -67,9 +67,10 @@ struct pmk_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> panel_ev;   // one pair per panel launch of the last fit
     int panel_n = 0;
     int num_cu = 0;                 // compute units of the device (sizes the persistent prediction grid)
-    // shader-clock probe: workgroup 0 of every factorisation step launch and of the prediction strip kernel leaves
-    // (shader cycles, 100 MHz ticks) of its own lifetime here: [2 l], [2 l + 1] for step launch l < 64, [128], [129]
-    // for the strip kernel.  The roofline's peak assumes the nominal clock; this says what the kernel actually got.
+    // shader-clock probe: workgroups 0..7 (one per XCD) of every factorisation step launch and of the prediction strip
+    // kernel leave (shader cycles, 100 MHz ticks) of their own lifetime here: block x of 130 pairs for XCD slot x:
+    // [2 l], [2 l + 1] for step launch l < 64, [128], [129] for the strip kernel.  The roofline's peak assumes the
+    // nominal clock; this says what the kernels actually got (every XCD has its own clock).
     unsigned long long *d_clk = nullptr;
     // pipelined kernel-matrix build: K1 runs block column by block column on a low-priority side stream while the
     // factorisation's step launches (which wait on the per-column events) keep the matrix pipes busy

@@ -177,9 +177,9 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
                                                                unsigned long long *__restrict__ clk)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // shader-clock probe: cycles and 10 ns ticks of workgroup 0's lifetime (pmk_ctx_shader_clock)
+    // shader-clock probe: cycles and 10 ns ticks of the lifetime of workgroups 0..7, one per XCD (pmk_ctx_shader_clock)
     unsigned long long c0 = 0, r0 = 0;
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (clk && blockIdx.x < 8 && threadIdx.x == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     real *V = strips + (int64_t)blockIdx.x * strip_stride + WCOLS * wave;   // this wave's columns, ld = TQ
     constexpr int PTS = (MAX_D + 1) * TILE;
     __shared__ real pts[3 * PTS];             // training points (SoA) and weights of three consecutive block rows
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
         // the next task reuses the strip: order its first stores after this task's last loads
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
-        clk[128] = __builtin_amdgcn_s_memtime() - c0;
-        clk[129] = __builtin_amdgcn_s_memrealtime() - r0;
+    if (clk && blockIdx.x < 8 && threadIdx.x == 0) {
+        clk[130 * blockIdx.x + 128] = __builtin_amdgcn_s_memtime() - c0;
+        clk[130 * blockIdx.x + 129] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 }
 
