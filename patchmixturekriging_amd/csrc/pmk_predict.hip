@@ -8,14 +8,16 @@
 // workgroup owns a strip of TQ = 256 query columns (8 waves x 32 columns: one workgroup per CU, two waves per
 // SIMD) and sweeps the block rows of L once for all of them.
 //
-// Strip task, block row i:  acc(128 x 32) = Kq_i - sum_{j<i} L[i,j] V_j   (gemm_nt, V_j re-read from the
+// Strip task, block row i:  acc(128 x 32) = Kq_i - sum_{j<i} L[i,j] V_j   (gemm_nt_indexed, V_j re-read from the
 // wave's strip in global memory, which is stored negated so the MFMA accumulates the subtraction)
-//                           -V_i = -L[ii]^-1 acc                          (tri_solve_inplace: block substitution)
+//                           -V_i = -L[ii]^-1 acc                          (tri_solve_global: block substitution,
+//                                                                          operands prefetched from the factor)
+// The schedule of a strip (what is kept off the critical path, and how) is described at the kernel.
 //
 // HBM traffic.  A strip streams the factor once (n^2/2 elements per TQ columns) and re-reads its own V block rows
 // (n^2/(2*128) elements per column).  The factor is the operand every strip of a region shares: strips of one region
-// that run at the same time on one XCD are kept in LOCK-STEP (a bounded spin on an arrival counter at the head of
-// every block row -- timing only, no data is handed over, so a missed rendezvous costs time, never correctness)
+// that run at the same time on one XCD are kept in LOCK-STEP (a bounded spin on an arrival counter once per block
+// row -- timing only, no data is handed over, so a missed rendezvous costs time, never correctness)
 // and the block row of L is then served to all of them by ONE fetch into that XCD's L2.
 #include <algorithm>
 #include <cstdlib>
