@@ -16,7 +16,8 @@ extern "C" {
 #endif
 
 /* C[I][J] (128 x 32, J contiguous: C[J + 32*I]) = sum_k MI[I + 128 k] MJ[J + 32 k],
- * k < K (K a multiple of 16), through gemm_nt<4,1,4> of one wave.  Host buffers. */
+ * k < K (K a multiple of 16), through the three forms of the wave-tile GEMM loop (gemm_nt, gemm_nt_indexed,
+ * gemm_nt_sbase) of one wave; elements on which they disagree come back as NaN.  Host buffers. */
 int pmk_selftest_gemm(pmk_ctx *ctx, int K, const double *MI, const double *MJ, double *C);
 /* T (128 x 32, T[J + 32*I]) <- -L^-1 T through tri_solve_inplace (operands staged in LDS) AND tri_solve_global (operands
  * prefetched from global memory); elements on which the two disagree come back as NaN.  L is 128 x 128 column-major

@@ -69,6 +69,120 @@ struct WaveTile {
 // loads it had issued a few instructions earlier (a wave alone on its SIMD ran at 73 % of the MFMA rate instead of
 // 90 %; tools/gemm_probe.hip).  Each I slot is refilled right behind the MFMAs that consumed it, so the loads of a
 // k-step are spread over its 16 MFMAs instead of queueing behind the last one.
+// Scalar-base form (tools/gemm_probe.hip: 98.7 % of the fp64 MFMA peak against 94.4 % for the same loop with vector
+// address arithmetic; a wave alone on its SIMD 97.6 % against 92.7 %).  On gfx950 a vector instruction is NOT hidden
+// behind another wave's -- or the same wave's -- MFMAs: 16 extra fp64 FMAs per k-step cost the loop 8.5 %, and so do
+// the handful of 64-bit address updates per k-step of the forms below.  Here every ring address is
+//     (wave-uniform base in scalar registers, advanced on the scalar ALU)  +  (one 32-bit byte offset per lane),
+// so the loop body holds nothing but MFMAs, loads and scalar adds.  The compiler does not emit that addressing mode
+// for this pattern; the loads are inline asm, which also means that the waits are ours: s_waitcnt vmcnt(LOADS (PF-1))
+// in front of every k-step (the ring registers are in/out operands of the wait, so no MFMA can be scheduled above it);
+// past the end of K the refills read the last k-step again, and the ring is drained after the loop -- no over-read.
+// Requirements: opI, opJ, ldI, ldJ wave-uniform; K a multiple of 4 PF, K >= 4 PF; the caller's own earlier loads are
+// consumed (waited for) before the call or never touch the ring.  Do NOT use where the compiler spills around the call:
+// it believes an asm load's destination is valid at once and could copy it to scratch before the wait.
+template <int NPI, int NPJ, int PF, int NACT = NPI>
+__device__ __forceinline__ void gemm_nt_sbase(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI, const real *opJ, int64_t ldJ,
+                                              int K, int lane)
+{
+    static_assert(PF == 4, "the unrolled waits below are written for a ring of 4 k-steps");
+    static_assert(NACT >= 1 && NACT <= 4 && NPJ >= 1 && NPJ <= 3, "ring shape");
+    constexpr int ES = (int)sizeof(real);
+    real2_t ra[PF][NACT], rb[PF][NPJ];
+    const uint32_t offI = (uint32_t)((2 * (lane & 15) + (int64_t)(lane >> 4) * ldI) * ES);
+    const uint32_t offJ = (uint32_t)((2 * (lane & 15) + (int64_t)(lane >> 4) * ldJ) * ES);
+    const char *bI = uniform_ptr(reinterpret_cast<const char *>(opI));
+    const char *bJ = uniform_ptr(reinterpret_cast<const char *>(opJ));
+    const int64_t sI = uniform_i64(4 * ldI * ES), sJ = uniform_i64(4 * ldJ * ES);
+#ifdef PMK_REAL_F32
+#define PMK_LDI(dst, pi) asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(offI), "s"(bI), "n"(32 * ES * (pi)))
+#define PMK_LDJ(dst, pj) asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 nt" : "=v"(dst) : "v"(offJ), "s"(bJ), "n"(32 * ES * (pj)))
+#else
+#define PMK_LDI(dst, pi) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(offI), "s"(bI), "n"(32 * ES * (pi)))
+#define PMK_LDJ(dst, pj) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(dst) : "v"(offJ), "s"(bJ), "n"(32 * ES * (pj)))
+#endif
+    // one k-step's refills / the wait in front of a k-step: every register of the slot is an in/out operand
+    auto refill_I = [&](int s, int pi) {
+        if (pi == 0) PMK_LDI(ra[s][0], 0);
+        if (NACT > 1 && pi == 1) PMK_LDI(ra[s][NACT > 1 ? 1 : 0], 1);
+        if (NACT > 2 && pi == 2) PMK_LDI(ra[s][NACT > 2 ? 2 : 0], 2);
+        if (NACT > 3 && pi == 3) PMK_LDI(ra[s][NACT > 3 ? 3 : 0], 3);
+    };
+    auto refill_J = [&](int s) {
+        PMK_LDJ(rb[s][0], 0);
+        if (NPJ > 1) PMK_LDJ(rb[s][NPJ > 1 ? 1 : 0], 1);
+        if (NPJ > 2) PMK_LDJ(rb[s][NPJ > 2 ? 2 : 0], 2);
+    };
+    constexpr int LOADS = NACT + NPJ;          // per k-step
+    // the wait in front of a k-step; every register of the slot passes through an (empty) asm behind it, so that no MFMA
+    // that reads the slot can be scheduled above the wait
+#define PMK_WAITV(n, s)                                                                         \
+    do {                                                                                        \
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[s][0]) : "n"(n));                          \
+        if (NACT > 1) asm volatile("" : "+v"(ra[s][NACT > 1 ? 1 : 0]));                         \
+        if (NACT > 2) asm volatile("" : "+v"(ra[s][NACT > 2 ? 2 : 0]));                         \
+        if (NACT > 3) asm volatile("" : "+v"(ra[s][NACT > 3 ? 3 : 0]));                         \
+        asm volatile("" : "+v"(rb[s][0]));                                                      \
+        if (NPJ > 1) asm volatile("" : "+v"(rb[s][NPJ > 1 ? 1 : 0]));                           \
+        if (NPJ > 2) asm volatile("" : "+v"(rb[s][NPJ > 2 ? 2 : 0]));                           \
+    } while (0)
+    auto mfmas = [&](int s, int pi) {
+#pragma unroll
+        for (int ei = 0; ei < 2; ++ei)
+#pragma unroll
+            for (int pj = 0; pj < NPJ; ++pj)
+#pragma unroll
+                for (int ej = 0; ej < 2; ++ej)
+                    t.f[2 * pi + ei][2 * pj + ej] = mfma_real(ra[s][pi][ei], rb[s][pj][ej], t.f[2 * pi + ei][2 * pj + ej]);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    const int nk = K / 4;                       // k-steps
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+#pragma unroll
+        for (int pi = 0; pi < NACT; ++pi) refill_I(s, pi);
+        refill_J(s);
+        if (s + 1 < PF || nk > PF) {            // after the prologue the bases point at k-step min(PF, nk - 1)
+            bI += sI;
+            bJ += sJ;
+        }
+    }
+    // refill r (counted from 0) fetches k-step min(PF + r, nk - 1): past the end the last k-step is simply read again
+    // (into registers nobody uses any more), which keeps the number of loads in flight -- and with it every wait of the
+    // loop -- the same in all passes, the last one included; the ring is drained after the loop
+    int left = nk - PF - 1;                     // base advances still allowed
+    for (int k0 = 0; k0 < K; k0 += 4 * PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            if (s == 0) PMK_WAITV(LOADS * 3, 0);
+            else if (s == 1) PMK_WAITV(LOADS * 3, 1);
+            else if (s == 2) PMK_WAITV(LOADS * 3, 2);
+            else PMK_WAITV(LOADS * 3, 3);
+#pragma unroll
+            for (int pi = 0; pi < NACT; ++pi) {
+                mfmas(s, pi);
+                __builtin_amdgcn_sched_barrier(0);
+                refill_I(s, pi);
+                if (pi == NACT - 1) refill_J(s);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bool adv = left > 0;
+            bI += adv ? sI : 0;
+            bJ += adv ? sJ : 0;
+            --left;
+        }
+    }
+    // drain: the (redundant) refills of the last pass are still in flight, and the compiler must not reuse their
+    // destination registers before they have landed
+    PMK_WAITV(0, 0);
+    PMK_WAITV(0, 1);
+    PMK_WAITV(0, 2);
+    PMK_WAITV(0, 3);
+#undef PMK_LDI
+#undef PMK_LDJ
+#undef PMK_WAITV
+}
+
 #ifndef PMK_PEEL_DEFAULT
 #define PMK_PEEL_DEFAULT false
 #endif

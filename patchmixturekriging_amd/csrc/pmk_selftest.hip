@@ -11,9 +11,13 @@ using namespace f64;
 __global__ __launch_bounds__(64) void selftest_gemm_kernel(int K, const double *MI, const double *MJ, double *C)
 {
     const int lane = threadIdx.x;
-    WaveTile<4, 1> t;
+    WaveTile<4, 1> t, u, v;
     t.zero();
+    u.zero();
+    v.zero();
     gemm_nt<4, 1, 4>(t, MI, 128, MJ, 32, K, lane);
+    gemm_nt_indexed<4, 1, 4>(u, MI, 128, MJ, 32, K, lane);       // the form the prediction kernel uses
+    gemm_nt_sbase<4, 1, 4>(v, MI, 128, MJ, 32, K, lane);         // scalar bases, asm loads, explicit waits
 #pragma unroll
     for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
@@ -22,7 +26,9 @@ __global__ __launch_bounds__(64) void selftest_gemm_kernel(int K, const double *
             for (int fj = 0; fj < 2; ++fj) {
                 const int I = 32 * (fi >> 1) + 2 * ((lane >> 4) + 4 * q) + (fi & 1);
                 const int J = 32 * (fj >> 1) + 2 * (lane & 15) + (fj & 1);
-                C[J + 32 * I] = t.f[fi][fj][q];
+                // the three loops issue the same MFMAs in the same order: any difference is a bug -> NaN
+                const bool same = t.f[fi][fj][q] == u.f[fi][fj][q] && t.f[fi][fj][q] == v.f[fi][fj][q];
+                C[J + 32 * I] = same ? t.f[fi][fj][q] : __builtin_nan("");
             }
 }
 

@@ -16,7 +16,7 @@ using namespace pmk::f64;
 
 // pointer-stepping variant: no per-step index clamp (the ring over-reads up to PF k-steps past K: callers guarantee
 // that memory exists), every I slot is refilled right behind the MFMAs that consumed it
-template <int NPI, int NPJ, int PFI, int PFJ, int NACT, int TOUCH = 0>
+template <int NPI, int NPJ, int PFI, int PFJ, int NACT, int TOUCH = 0, int NV = 0>
 __device__ __forceinline__ void gemm_v2(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI, const real *opJ, int64_t ldJ,
                                         int K, int lane)
 {
@@ -30,6 +30,8 @@ __device__ __forceinline__ void gemm_v2(WaveTile<NPI, NPJ> &t, const real *opI, 
     const real *tI = opI + (int64_t)TOUCH * sI;
     const int tw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int junk = 0;
+    double dv[4] = {1.0, 2.0, 3.0, 4.0};      // NV > 0: independent fp64 FMAs between the MFMAs (does VALU work hide in the MFMA shadow?)
+    const double da = 1.0000001, db = 1e-9;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < PFJ; ++s) {
@@ -62,6 +64,11 @@ __device__ __forceinline__ void gemm_v2(WaveTile<NPI, NPJ> &t, const real *opI, 
                     for (int pj = 0; pj < NPJ; ++pj)
                         rb[s][pj] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(qJ + 32 * pj));
                 }
+                if (NV) {
+#pragma unroll
+                    for (int u = 0; u < NV / NACT; ++u)
+                        asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(dv[u & 3]) : "v"(da), "v"(db));
+                }
                 if (TOUCH && pi == 0) {
                     // column (tw >> 1) of the k-step, rows 64 (tw & 1) .. +63: 4 lines of 128 B
                     const real *tp = tI + (int64_t)(tw >> 1) * ldI + 64 * (tw & 1);
@@ -77,6 +84,69 @@ __device__ __forceinline__ void gemm_v2(WaveTile<NPI, NPJ> &t, const real *opI, 
         }
     }
     if (TOUCH) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(junk));
+    if (NV) t.f[0][0][0] += (dv[0] + dv[1] + dv[2] + dv[3]) * 1e-300;
+}
+
+// scalar-base form: every address of the rings is (wave-uniform base in SGPRs) + (one 32-bit byte offset per lane);
+// the bases advance on the scalar ALU, so the loop body holds NO vector instruction besides the MFMAs and the loads.
+// The loads are inline asm (the compiler does not emit the saddr form for this pattern), so the waits are explicit:
+// vmcnt(5 (PF - 1)) in front of every k-step; the last PF k-steps run without loads and the ring is drained there.
+template <int PF>
+__device__ __forceinline__ void gemm_v3(WaveTile<4, 1> &t, const real *opI, int64_t ldI, const real *opJ, int64_t ldJ, int K, int lane)
+{
+    real2_t ra[PF][4], rb[PF];
+    const uint32_t offI = (uint32_t)((2 * (lane & 15) + (int64_t)(lane >> 4) * ldI) * 8);
+    const uint32_t offJ = (uint32_t)((2 * (lane & 15) + (int64_t)(lane >> 4) * ldJ) * 8);
+    const char *bI = uniform_ptr(reinterpret_cast<const char *>(opI));
+    const char *bJ = uniform_ptr(reinterpret_cast<const char *>(opJ));
+    const int64_t sI = uniform_i64(4 * ldI * 8), sJ = uniform_i64(4 * ldJ * 8);
+#define LDI(dst, pi) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(offI), "s"(bI), "n"(256 * (pi)))
+#define LDJ(dst) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(offJ), "s"(bJ))
+#define WAITV(n, s) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(ra[s][0]), "+v"(ra[s][1]), "+v"(ra[s][2]), "+v"(ra[s][3]), "+v"(rb[s]))
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        LDI(ra[s][0], 0); LDI(ra[s][1], 1); LDI(ra[s][2], 2); LDI(ra[s][3], 3);
+        LDJ(rb[s]);
+        bI += sI; bJ += sJ;
+    }
+    auto mfmas = [&](int s, int pi) {
+#pragma unroll
+        for (int ei = 0; ei < 2; ++ei)
+#pragma unroll
+            for (int ej = 0; ej < 2; ++ej)
+                t.f[2 * pi + ei][ej] = mfma_real(ra[s][pi][ei], rb[s][ej], t.f[2 * pi + ei][ej]);
+    };
+    static_assert(PF == 4, "wait counts below are written for PF = 4");
+    for (int k0 = 0; k0 < K - 16; k0 += 16) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            if (s == 0) WAITV(15, 0); else if (s == 1) WAITV(15, 1); else if (s == 2) WAITV(15, 2); else WAITV(15, 3);
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) {
+                mfmas(s, pi);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pi == 0) LDI(ra[s][0], 0); else if (pi == 1) LDI(ra[s][1], 1); else if (pi == 2) LDI(ra[s][2], 2); else { LDI(ra[s][3], 3); LDJ(rb[s]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bI += sI; bJ += sJ;
+        }
+    }
+    // last PF k-steps: no refills; 15, 10, 5, 0 loads may still be in flight in front of each
+    WAITV(15, 0);
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi) mfmas(0, pi);
+    WAITV(10, 1);
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi) mfmas(1, pi);
+    WAITV(5, 2);
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi) mfmas(2, pi);
+    WAITV(0, 3);
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi) mfmas(3, pi);
+#undef LDI
+#undef LDJ
+#undef WAITV
 }
 
 template <int VAR>
@@ -100,6 +170,9 @@ __global__ __launch_bounds__(512, 2) void probe(const double *__restrict__ L, in
         if (VAR == 5) gemm_v2<4, 1, 4, 4, 4, 12>(acc, Li, ld, V, 256, K, lane);
         if (VAR == 6) gemm_v2<4, 1, 4, 8, 4, 12>(acc, Li, ld, V, 256, K, lane);
         if (VAR == 7) gemm_v2<4, 1, 4, 8, 4, 24>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 8) gemm_v2<4, 1, 4, 4, 4, 0, 16>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 9) gemm_v2<4, 1, 4, 4, 4, 0, 48>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 10) gemm_v3<4>(acc, Li, ld, V, 256, K, lane);
         __syncthreads();
     }
     double s = 0;
@@ -209,6 +282,9 @@ int main(int argc, char **argv)
         run<5>("pointer stepping PFI 4 PFJ 4, L2 touch 12 ahead", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
         run<6>("pointer stepping PFI 4 PFJ 8, L2 touch 12 ahead", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
         run<7>("pointer stepping PFI 4 PFJ 8, L2 touch 24 ahead", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<8>("pointer stepping 4/4 + 16 fp64 FMAs per k-step", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<9>("pointer stepping 4/4 + 48 fp64 FMAs per k-step", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<10>("scalar bases, asm loads, explicit waits", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
     }
     run_wide<4, 4>("128 x 64 tile, 1 wave/SIMD, PFI 4 PFJ 4", L, ld, rs, strips, ss, K, reps, sink, nwg);
     run_wide<8, 8>("128 x 64 tile, 1 wave/SIMD, PFI 8 PFJ 8", L, ld, rs, strips, ss, K, reps, sink, nwg);
