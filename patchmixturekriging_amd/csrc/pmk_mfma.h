@@ -81,7 +81,7 @@ struct WaveTile {
 // Requirements: opI, opJ, ldI, ldJ wave-uniform; K a multiple of 4 PF, K >= 4 PF; the caller's own earlier loads are
 // consumed (waited for) before the call or never touch the ring.  Do NOT use where the compiler spills around the call:
 // it believes an asm load's destination is valid at once and could copy it to scratch before the wait.
-template <int NPI, int NPJ, int PF, int NACT = NPI>
+template <int NPI, int NPJ, int PF, int NACT = NPI, bool PEEL = false>
 __device__ __forceinline__ void gemm_nt_sbase(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI, const real *opJ, int64_t ldJ,
                                               int K, int lane)
 {
@@ -151,7 +151,7 @@ __device__ __forceinline__ void gemm_nt_sbase(WaveTile<NPI, NPJ> &t, const real 
     // (into registers nobody uses any more), which keeps the number of loads in flight -- and with it every wait of the
     // loop -- the same in all passes, the last one included; the ring is drained after the loop
     int left = nk - PF - 1;                     // base advances still allowed
-    for (int k0 = 0; k0 < K; k0 += 4 * PF) {
+    auto pass = [&]() {                           // PF k-steps
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
             if (s == 0) PMK_WAITV(LOADS * 3, 0);
@@ -171,7 +171,9 @@ __device__ __forceinline__ void gemm_nt_sbase(WaveTile<NPI, NPJ> &t, const real 
             bJ += adv ? sJ : 0;
             --left;
         }
-    }
+    };
+    if (PEEL) pass();                             // see gemm_nt: keeps the compiler's own waits out of the loop
+    for (int k0 = PEEL ? 4 * PF : 0; k0 < K; k0 += 4 * PF) pass();
     // drain: the (redundant) refills of the last pass are still in flight, and the compiler must not reuse their
     // destination registers before they have landed
     PMK_WAITV(0, 0);
