@@ -149,6 +149,55 @@ __device__ __forceinline__ void gemm_v3(WaveTile<4, 1> &t, const real *opI, int6
 #undef WAITV
 }
 
+// buffer-load form: scalar resource descriptors + one 32-bit lane offset + a scalar k offset (soffset): no vector
+// address arithmetic in the loop, and -- unlike the asm form -- the loads are builtins, so the compiler tracks their
+// waits itself (safe where it spills).  Offsets are 32-bit: K * ld * 8 must stay below 2^31.
+typedef int int4_v __attribute__((ext_vector_type(4)));
+template <int PF>
+__device__ __forceinline__ void gemm_buf(WaveTile<4, 1> &t, const real *opI, int64_t ldI, const real *opJ, int64_t ldJ, int K, int lane)
+{
+    real2_t ra[PF][4], rb[PF];
+    const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(opI), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rJ = __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(opJ), 0, 0x7fffffff, 0x00020000);
+    const int vI = (int)((2 * (lane & 15) + (int64_t)(lane >> 4) * ldI) * 8);
+    const int vJ = (int)((2 * (lane & 15) + (int64_t)(lane >> 4) * ldJ) * 8);
+    const int sI = __builtin_amdgcn_readfirstlane((int)(4 * ldI * 8)), sJ = __builtin_amdgcn_readfirstlane((int)(4 * ldJ * 8));
+    int oI = 0, oJ = 0;            // scalar byte offsets of the next k-step to load
+    auto ldI4 = [&](int pi) { return __builtin_bit_cast(real2_t, __builtin_amdgcn_raw_buffer_load_b128(rI, vI + 256 * pi, oI, 0)); };
+    auto ldJ1 = [&]() { return __builtin_bit_cast(real2_t, __builtin_amdgcn_raw_buffer_load_b128(rJ, vJ, oJ, 2)); };
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) ra[s][pi] = ldI4(pi);
+        rb[s] = ldJ1();
+        oI += sI; oJ += sJ;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int endI = __builtin_amdgcn_readfirstlane((int)((K / 4 - 1) * (4 * ldI * 8))), endJ = __builtin_amdgcn_readfirstlane((int)((K / 4 - 1) * (4 * ldJ * 8)));
+    for (int k0 = 0; k0 < K; k0 += 4 * PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) {
+#pragma unroll
+                for (int ei = 0; ei < 2; ++ei)
+#pragma unroll
+                    for (int ej = 0; ej < 2; ++ej)
+                        t.f[2 * pi + ei][ej] = mfma_real(ra[s][pi][ei], rb[s][ej], t.f[2 * pi + ei][ej]);
+                const int cI = oI < endI ? oI : endI;           // past the end: the last k-step again
+                ra[s][pi] = __builtin_bit_cast(real2_t, __builtin_amdgcn_raw_buffer_load_b128(rI, vI + 256 * pi, cI, 0));
+                if (pi == 3) {
+                    const int cJ = oJ < endJ ? oJ : endJ;
+                    rb[s] = __builtin_bit_cast(real2_t, __builtin_amdgcn_raw_buffer_load_b128(rJ, vJ, cJ, 2));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            oI += sI; oJ += sJ;
+        }
+    }
+}
+
 template <int VAR>
 __global__ __launch_bounds__(512, 2) void probe(const double *__restrict__ L, int64_t ld, int64_t region_stride,
                                                 const double *__restrict__ strips, int64_t strip_stride, int K, int reps,
@@ -173,6 +222,7 @@ __global__ __launch_bounds__(512, 2) void probe(const double *__restrict__ L, in
         if (VAR == 8) gemm_v2<4, 1, 4, 4, 4, 0, 16>(acc, Li, ld, V, 256, K, lane);
         if (VAR == 9) gemm_v2<4, 1, 4, 4, 4, 0, 48>(acc, Li, ld, V, 256, K, lane);
         if (VAR == 10) gemm_v3<4>(acc, Li, ld, V, 256, K, lane);
+        if (VAR == 11) gemm_buf<4>(acc, Li, ld, V, 256, K, lane);
         __syncthreads();
     }
     double s = 0;
@@ -285,6 +335,7 @@ int main(int argc, char **argv)
         run<8>("pointer stepping 4/4 + 16 fp64 FMAs per k-step", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
         run<9>("pointer stepping 4/4 + 48 fp64 FMAs per k-step", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
         run<10>("scalar bases, asm loads, explicit waits", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
+        run<11>("buffer loads: scalar descriptor + soffset", threads, L, ld, rs, strips, ss, K, reps, sink, nwg);
     }
     run_wide<4, 4>("128 x 64 tile, 1 wave/SIMD, PFI 4 PFJ 4", L, ld, rs, strips, ss, K, reps, sink, nwg);
     run_wide<8, 8>("128 x 64 tile, 1 wave/SIMD, PFI 8 PFJ 8", L, ld, rs, strips, ss, K, reps, sink, nwg);
