@@ -465,7 +465,9 @@ void pmk_model_destroy(pmk_model *m)
     if (!m) return;
     dev_free(m->d_desc); dev_free(m->d_info); dev_free(m->d_hv); dev_free(m->d_hc); dev_free(m->d_pre);
     dev_free(m->d_order);
-    for (void **p : {&m->d_x, &m->d_y, &m->d_z, &m->d_c, &m->d_a, &m->d_inv, &m->d_strip, &m->d_partial, &m->d_solve_part}) {
+    dev_free(m->d_sched);
+    dev_free(m->d_sched_init);
+    for (void **p : {&m->d_qtasks, &m->d_x, &m->d_y, &m->d_z, &m->d_c, &m->d_a, &m->d_inv, &m->d_strip, &m->d_partial, &m->d_solve_part}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -554,6 +556,9 @@ int pmk_model_create_ex(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const 
         m->active_prefix.assign((size_t)m->max_nt + 2, 0);
         for (int64_t r = 0; r < P; ++r)
             for (int t = 0; t <= m->desc[(size_t)r].nt; ++t) ++m->active_prefix[(size_t)t];
+        m->order = order;
+        if (const char *e = std::getenv("PMK_CHOL_QUEUE")) m->queue_mode = std::atoi(e) != 0;     // A/B switches
+        if (const char *e = std::getenv("PMK_QUEUE_FROM")) m->queue_from = std::atoi(e);
         if (hipMemcpy(m->d_order, order.data(), sizeof(int32_t) * (size_t)P, hipMemcpyHostToDevice) != hipSuccess) {
             set_error("pmk_model_create: upload failed");
             pmk_model_destroy(m);
@@ -654,7 +659,37 @@ int pmk_model_info(pmk_model *m, int32_t *info)
     if (!m || !info) { set_error("pmk_model_info: NULL argument"); return -1; }
     PMK_HIP(hipSetDevice(m->ctx->device));
     PMK_HIP(hipMemcpyAsync(info, m->d_info, sizeof(int32_t) * (size_t)m->P, hipMemcpyDeviceToHost, m->ctx->stream));
+    constexpr int SCHED_HEADS = 16;                 // pmk_chol.hip: error word, then 8 list heads per segment
+    std::vector<int32_t> sched((size_t)SCHED_HEADS + 8 * 16, 0);
+    if (m->queue_used)
+        PMK_HIP(hipMemcpyAsync(sched.data(), m->d_sched, sizeof(int32_t) * sched.size(), hipMemcpyDeviceToHost, m->ctx->stream));
     PMK_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (m->queue_used) {
+        // the task-queue factorisation: no time-out, and every XCD's list drained
+        bool drained = sched[0] == 0;
+        for (int sg = 0; sg < m->qsegs; ++sg)
+            for (int x = 0; x < 8; ++x)
+                drained = drained && sched[(size_t)SCHED_HEADS + 8 * sg + x] >= m->qoff[(size_t)sg * 9 + x + 1] - m->qoff[(size_t)sg * 9 + x];
+        if (!drained) {
+            if (std::getenv("PMK_QUEUE_DEBUG")) {
+                std::fprintf(stderr, "queue: err %d", sched[0]);
+                for (int x = 0; x < 8; ++x)
+                    std::fprintf(stderr, " | head %d of %d", sched[(size_t)SCHED_HEADS + x], m->qoff[(size_t)x + 1] - m->qoff[(size_t)x]);
+                std::fprintf(stderr, "\n");
+                std::vector<int32_t> fl((size_t)m->P * (size_t)m->qfstride);
+                if (hipMemcpy(fl.data(), m->d_sched + 16 + 8 * 16, sizeof(int32_t) * fl.size(), hipMemcpyDeviceToHost) == hipSuccess)
+                    for (int64_t r = 0; r < m->P; ++r) {
+                        const int32_t *f = fl.data() + (size_t)r * (size_t)m->qfstride;
+                        if (f[0] >= m->desc[(size_t)r].nt) continue;
+                        std::fprintf(stderr, "patch %lld nt %d: diag %d look %d rows", (long long)r, m->desc[(size_t)r].nt, f[0], f[m->qfstride - 1]);
+                        for (int i = 0; i < m->desc[(size_t)r].nt; ++i) std::fprintf(stderr, " %d", f[1 + i]);
+                        std::fprintf(stderr, "\n");
+                    }
+            }
+            set_error("pmk_model_fit: the factorisation's task queue did not complete (error word %d)", sched[0]);
+            return -101;
+        }
+    }
     int worst = 0;
     for (int64_t r = 0; r < m->P; ++r) {
         // a failure inside the identity padding cannot happen; clamp to the patch size for safety

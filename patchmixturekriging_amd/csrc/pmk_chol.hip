@@ -50,6 +50,56 @@ constexpr int PARTIAL_TILE = TILE * TILE / 2;      // a 128 x 128 partial produc
 static_assert(POTRF_END <= TRI_LDS_DOUBLES, "potrf scratch must fit into the TRSM operand array");
 
 // ---------------------------------------------------------------------------------------------
+// Stores of the task-queue path (chol_queue_kernel): a tile that another workgroup of the SAME launch will read is
+// written through (sc1: the bytes leave the XCD's L2 at once), so the hand-off needs no release fence -- every storing
+// wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, one lane sets the flag, and the consumer
+// invalidates its L1 once behind its poll (MI355X_MICROARCH.md, inter-workgroup visibility, form R1).  The asm stores
+// are invisible to the compiler's wait counting, which only makes its own counted waits stricter.
+// ---------------------------------------------------------------------------------------------
+template <bool SC1>
+__device__ __forceinline__ void put2(real *p, real2_t v)
+{
+    if (SC1) {
+#ifdef PMK_REAL_F32
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+    } else {
+        *reinterpret_cast<real2_t *>(p) = v;
+    }
+}
+template <bool SC1>
+__device__ __forceinline__ void put1(real *p, real v)
+{
+    if (SC1) {
+#ifdef PMK_REAL_F32
+        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+    } else {
+        *p = v;
+    }
+}
+// a load the compiler keeps on the vector path (and re-issues every time)
+__device__ __forceinline__ real load_volatile(const real *p) { return *reinterpret_cast<const volatile real *>(p); }
+// all stores of this wave have left (the asm stores above included)
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Entered by all threads of the workgroup: every wave's stores drained, then this CU's L1 dropped, so that plain loads
+// behind it see what the workgroup itself -- or, behind a matched poll, another workgroup -- has written through.
+__device__ __forceinline__ void workgroup_refresh()
+{
+    drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // potrf of one 128 x 128 diagonal tile (already updated, lower part in the slab at Akk), right-looking, the tile
 // distributed over the registers of all 256 threads: thread (tr, tc) of a 16 x 16 grid holds
 // A[tr + 16 a][tc + 16 b], a, b < 8; the threads with tr == 0 also carry the right-hand side (lds[POTRF_RHS + 0..127],
@@ -61,6 +111,7 @@ static_assert(POTRF_END <= TRI_LDS_DOUBLES, "potrf scratch must fit into the TRS
 // blocks (operands of every later block substitution), z, and info (first non-positive pivot, 1-based, once).
 // Must be entered by all 256 threads; the caller has synchronised after its last write to Akk and rhs.
 // ---------------------------------------------------------------------------------------------
+template <bool SC1 = false>
 __device__ __forceinline__ void tile_potrf(real *__restrict__ Akk, int64_t ld, real *lds,
                                            real *__restrict__ ninv_k, real *__restrict__ z_k,
                                            int32_t *__restrict__ info_p, int k)
@@ -69,7 +120,9 @@ __device__ __forceinline__ void tile_potrf(real *__restrict__ Akk, int64_t ld, r
 #define COL(i) lds[POTRF_COL + (i)]
 #define SDIAG lds[POTRF_SDIAG]
 #define SBAD lds[POTRF_BAD]          /* first failed pivot (1-based) as a real: exact up to 2^24 */
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));       // opaque per call: nothing lane-dependent is hoisted out of a caller's task loop
+    const int lane = tid & 63, wave = tid >> 6;
     const int tr = tid & 15, tc = tid >> 4;
     real a_[8][8], rr[8];
 #pragma unroll
@@ -141,12 +194,12 @@ __device__ __forceinline__ void tile_potrf(real *__restrict__ Akk, int64_t ld, r
         for (int b2 = 0; b2 < 8; ++b2) {
             const int r = tr + 16 * a, c = tc + 16 * b2;
             const real v = (b2 <= a && r >= c) ? a_[a][b2] : (real)0;
-            Akk[r + (int64_t)c * ld] = v;
+            put1<SC1>(Akk + r + (int64_t)c * ld, v);
             if ((r >> 5) == (c >> 5)) DBLK(r >> 5, r & 31, c & 31) = v;
         }
     if (tr == 0) {
 #pragma unroll
-        for (int b2 = 0; b2 < 8; ++b2) z_k[tc + 16 * b2] = rr[b2];
+        for (int b2 = 0; b2 < 8; ++b2) put1<SC1>(z_k + tc + 16 * b2, rr[b2]);
     }
     __syncthreads();
     if (tid == 0 && SBAD != (real)0 && *info_p == 0) *info_p = (int32_t)SBAD;
@@ -163,7 +216,7 @@ __device__ __forceinline__ void tile_potrf(real *__restrict__ Akk, int64_t ld, r
         }
         real *Ni = ninv_k + (int64_t)wave * (SB * SB);
 #pragma unroll
-        for (int i = 0; i < SB; ++i) Ni[i + SB * c] = (i >= c) ? -xcol[i] : (real)0;
+        for (int i = 0; i < SB; ++i) put1<SC1>(Ni + i + SB * c, (i >= c) ? -xcol[i] : (real)0);
     }
 #undef DBLK
 #undef COL
@@ -205,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void chol_first_kernel(const PatchDesc *__r
 // substitution.  SPLIT: the deep product arrives as `nsplit` partial tiles instead (chol_partial_kernel).
 // Entered by all threads; contains one barrier (after the staging of the TRSM operands in `lds`); the caller
 // synchronises before `lds` is reused.
-template <int SPLIT>
+template <int SPLIT, bool SC1 = false>
 __device__ __forceinline__ void block_row_update(const PatchDesc &pd, real *__restrict__ S, const real *__restrict__ ninv_p,
                                                  int k, int row, real *lds, const real2_t *__restrict__ pt, int nsplit)
 {
@@ -274,7 +327,7 @@ __device__ __forceinline__ void block_row_update(const PatchDesc &pd, real *__re
             real2_t o;
             o[0] = acc.f[fi][0][q];
             o[1] = acc.f[fi][1][q];
-            *reinterpret_cast<real2_t *>(out + cl * ld) = o;
+            put2<SC1>(out + cl * ld, o);
         }
 }
 
@@ -282,18 +335,23 @@ __device__ __forceinline__ void block_row_update(const PatchDesc &pd, real *__re
 //     A[k+1,k+1] -= L[k+1,0:k+1] L[k+1,0:k+1]^T,    rhs = y_{k+1} - L[k+1,0:k+1] z_{0:k+1},
 // then the potrf of the tile (-> L[k+1,k+1], its -D^-1 blocks, z_{k+1}).  Entered after a barrier that follows the
 // stores of L[k+1, k] (same CU: visible through its L1) and the last use of `lds`.
-template <int SPLIT>
-__device__ __forceinline__ void lookahead_potrf(const PatchDesc &pd, real *__restrict__ S, real *__restrict__ ninv_p,
-                                                const real *__restrict__ y_p, real *__restrict__ z_p,
-                                                int32_t *__restrict__ info_p, int k, real *lds,
-                                                const real2_t *__restrict__ pt, int nsplit)
+// Generalised to a range of block columns [cb, ce) of block row t = k + 1 (the task queue applies columns 0 .. k - 1 as
+// soon as they are final and column k inside the potrf task): rhs_src = the right-hand side so far (y_t, or what an
+// earlier range left), rhs_dst = where this range leaves it (nullptr: in LDS, for the potrf that follows).  The
+// right-hand side is reduced block column by block column, so that any split of the range gives the same bits.
+template <int SPLIT, bool SC1 = false>
+__device__ __forceinline__ void lookahead_update(const PatchDesc &pd, real *__restrict__ S,
+                                                 const real *rhs_src, const real *z_p, int k, real *lds,
+                                                 const real2_t *__restrict__ pt, int nsplit, int cb, int ce,
+                                                 real *rhs_dst = nullptr)
 {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));                     // see block_row_update
     const int lane = tid & 63, wave = tid >> 6;
     const int64_t ld = pd.ld;
     const int64_t c0 = (int64_t)k * TILE, t0 = c0 + TILE;
-    const int K2 = (k + 1) * TILE;                    // block columns 0..k
+    const int K2 = (ce - cb) * TILE;                  // depth of this range
+    const int64_t cs = (int64_t)cb * TILE;            // its first column
     const int h = wave >> 1, g = wave & 1;            // 64-row half, 64-column half of the tile
     real *Att = S + t0 + t0 * ld;
     if (SPLIT) {
@@ -347,7 +405,7 @@ __device__ __forceinline__ void lookahead_potrf(const PatchDesc &pd, real *__res
                     acc.f[fi][2 * pj][q] = -a[0];
                     acc.f[fi][2 * pj + 1][q] = -a[1];
                 }
-        gemm_nt<2, 2, PF_DIAG>(acc, S + t0 + 64 * g, ld, S + t0 + 64 * h, ld, K2, lane);
+        if (K2 > 0) gemm_nt<2, 2, PF_DIAG>(acc, S + t0 + 64 * g + cs * ld, ld, S + t0 + 64 * h + cs * ld, ld, K2, lane);
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi)
 #pragma unroll
@@ -359,28 +417,46 @@ __device__ __forceinline__ void lookahead_potrf(const PatchDesc &pd, real *__res
                     real2_t a;
                     a[0] = -acc.f[fi][2 * pj][q];
                     a[1] = -acc.f[fi][2 * pj + 1][q];
-                    *reinterpret_cast<real2_t *>(Att + rl + (int64_t)cl * ld) = a;
+                    put2<SC1>(Att + rl + (int64_t)cl * ld, a);
                 }
     } else {
         // the wave without a GEMM sub-tile does the forward-solve right-hand side, two rows per lane
         const real *Lr = S + t0 + 2 * lane;
-        real2_t s0 = {0.0, 0.0}, s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, s3 = {0.0, 0.0};
-        for (int c = 0; c < K2; c += 16) {     // 16 independent column loads in flight per batch
-            real2_t av[16];
+        real2_t r = *reinterpret_cast<const real2_t *>(rhs_src + 2 * lane);
+        for (int jb = cb; jb < ce; ++jb) {
+            real2_t s0 = {0.0, 0.0}, s1 = {0.0, 0.0}, s2 = {0.0, 0.0}, s3 = {0.0, 0.0};
+            for (int c = jb * TILE; c < (jb + 1) * TILE; c += 16) {     // 16 independent column loads in flight per batch
+                real2_t av[16];
+                real zv[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) av[u] = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + u) * ld);
+                for (int u = 0; u < 16; ++u) av[u] = *reinterpret_cast<const real2_t *>(Lr + (int64_t)(c + u) * ld);
+                // z comes from other workgroups of the same launch in the queue form: vector loads (a uniform index on
+                // a const restrict pointer would go through the scalar cache, which no acquire refreshes)
 #pragma unroll
-            for (int u = 0; u < 16; u += 4) {
-                s0 += av[u] * z_p[c + u]; s1 += av[u + 1] * z_p[c + u + 1];
-                s2 += av[u + 2] * z_p[c + u + 2]; s3 += av[u + 3] * z_p[c + u + 3];
+                for (int u = 0; u < 16; ++u) zv[u] = SC1 ? load_volatile(z_p + c + u) : z_p[c + u];
+#pragma unroll
+                for (int u = 0; u < 16; u += 4) {
+                    s0 += av[u] * zv[u]; s1 += av[u + 1] * zv[u + 1];
+                    s2 += av[u + 2] * zv[u + 2]; s3 += av[u + 3] * zv[u + 3];
+                }
             }
+            r -= (s0 + s1) + (s2 + s3);
         }
-        const real2_t sum = (s0 + s1) + (s2 + s3);
-        const real2_t yy = *reinterpret_cast<const real2_t *>(y_p + t0 + 2 * lane);
-        *reinterpret_cast<real2_t *>(lds + POTRF_RHS + 2 * lane) = yy - sum;
+        if (rhs_dst) put2<SC1>(rhs_dst + 2 * lane, r);
+        else *reinterpret_cast<real2_t *>(lds + POTRF_RHS + 2 * lane) = r;
     }
+}
+
+template <int SPLIT>
+__device__ __forceinline__ void lookahead_potrf(const PatchDesc &pd, real *__restrict__ S, real *__restrict__ ninv_p,
+                                                const real *__restrict__ y_p, real *__restrict__ z_p,
+                                                int32_t *__restrict__ info_p, int k, real *lds,
+                                                const real2_t *__restrict__ pt, int nsplit)
+{
+    lookahead_update<SPLIT, false>(pd, S, y_p + (int64_t)(k + 1) * TILE, z_p, k, lds, pt, nsplit, 0, k + 1);
     __syncthreads();
-    tile_potrf(Att, ld, lds, ninv_p + (int64_t)(k + 1) * (4 * SB * SB), z_p + t0, info_p, k + 1);
+    const int64_t t0 = (int64_t)(k + 1) * TILE;
+    tile_potrf<false>(S + t0 + t0 * pd.ld, pd.ld, lds, ninv_p + (int64_t)(k + 1) * (4 * SB * SB), z_p + t0, info_p, k + 1);
 }
 
 // (patch slot, block row) of a step-type launch from the hardware block id.  Blocks are dealt round-robin over the 8
@@ -470,6 +546,292 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
     if (probe) {
         clk[130 * blockIdx.x + 2 * launch] = __builtin_amdgcn_s_memtime() - c0;
         clk[130 * blockIdx.x + 2 * launch + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Task-queue form of the same factorisation: ONE launch for all block columns (opt-in: PMK_CHOL_QUEUE=1; measured
+// SLOWER than the step launches at config C, profiles/r03_fit_experiments.txt -- kept as the experiment it is, with its
+// timeline tool tools/queue_trace.py).
+//
+// The step launches above are global barriers: every launch ends with half-empty CUs (the last workgroups of a
+// launch finish ~100 us apart) and starts cold, 15 times per fit at config C.  Here the work of all launches is one
+// list of tasks per XCD -- POT (potrf of a diagonal tile, after the last block column of its block row has been
+// applied to it), ROW (one block row of one block column) and LOOK (the earlier block columns applied to the next
+// diagonal tile and its right-hand side as soon as they are final) -- and a resident grid of workgroups (two per CU)
+// pulls tasks from the list of the XCD it runs on (HW_REG_XCC_ID) with one returning atomic add.  Dependencies are
+// per-patch words in global memory:
+//     flag[0]           = number of diagonal tiles factorised (potrf k done, -D^-1 blocks and z_k out  =>  k + 1)
+//     flag[1 + i]       = number of block columns of block row i that are final
+//     flag[fstride - 1] = the diagonal tile whose look-ahead (block columns 0 .. t - 2) is done
+// The list is in an order in which everything a task waits for comes EARLIER in the same list, and a task is only
+// held by a running workgroup, so the earliest unfinished task can always proceed: no assumption about dispatch order
+// or residency is needed for progress, and none about placement for correctness (every hand-off is write-through
+// stores -> drained -> barrier -> flag, poll -> L1 invalidate -> barrier -> loads).  The lists are per XCD because the
+// block rows of a patch stream the same block row k of L: one L2 then fetches it once -- a speed choice; a workgroup
+// only serves the list of its own XCD, and the host checks after the launch that every list was drained (an XCD
+// without workgroups would leave its list untouched).  Spins are bounded (QUEUE_SPIN_TICKS of the 100 MHz clock); a
+// time-out sets the error word, every workgroup then stops pulling and the host reports the fit as failed.
+// The loop keeps its barriers out of divergent control flow: the scalar work (flags, dequeue, polls) sits in a region
+// of wave 0 that is closed before the barrier that follows it (with the flags raised at the loop TAIL the compiler
+// merged tail and head regions and moved a barrier into a divergent loop: stale control words, wild task indices).
+// ---------------------------------------------------------------------------------------------
+struct CholTask {
+    int32_t pid;        // patch
+    int16_t k;          // block column
+    int16_t row;        // block row (ROW, CRIT: k + 1)
+    int32_t type;       // QT_*
+    int32_t pad_;
+};
+// POT: potrf of diagonal tile k (k = 0: as K1 left it; k >= 1: block column k - 1 of its block row is applied first);
+// ROW: block row `row` of block column k; LOOK: block columns 0 .. k - 2 applied to diagonal tile k and to its
+// right-hand side (k >= 2), as soon as block row k is final that far
+constexpr int QT_POT = 0, QT_ROW = 1, QT_LOOK = 2;
+struct QueueOffsets { int32_t off[9]; };                 // list of XCD x = tasks[off[x] .. off[x + 1])
+constexpr int QUEUE_MAX_SEGS = 16;      // the task lists may be cut into several launches (PMK_QUEUE_SEGS, experiments)
+constexpr int SCHED_ERR = 0, SCHED_HEADS = 16, SCHED_FLAGS = 16 + 8 * QUEUE_MAX_SEGS;      // int32 words of the scheduling block
+constexpr unsigned long long QUEUE_SPIN_TICKS = 300000000ull;       // 3 s
+
+#ifdef PMK_QTRACE
+// diagnostic build only (make variant VFLAGS=-DPMK_QTRACE): per task {start, deps met, end} in 100 MHz ticks + where
+constexpr int QTRACE_WORDS = 4, QTRACE_MAX = 1 << 18;
+__device__ unsigned long long g_qtrace[QTRACE_WORDS * QTRACE_MAX];
+#define PMK_QSTAMP(i)                                                                                       \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && gtask < QTRACE_MAX) g_qtrace[QTRACE_WORDS * gtask + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define PMK_QSTAMP(i)
+#endif
+
+// thread 0 only: wait until *p >= need; false on timeout or when another workgroup has raised the error word
+__device__ __forceinline__ bool spin_until_ge(const int32_t *p, int need, const int32_t *err)
+{
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(16);
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > QUEUE_SPIN_TICKS) return false;
+    }
+}
+
+// the flags a task waits for before it starts (fl = the patch's flag words, look = index of its look-ahead word):
+//   ROW (k, row): block row k and block row `row` final through column k - 1 (the diagonal tile k is waited for later)
+//   LOOK (t)    : block row t final through column t - 2, and LOOK (t - 1) done (one word per patch counts them: they
+//                 must finish in order)
+//   POT (t >= 1): block row t final through column t - 1, and LOOK (t) done (t >= 2)
+__device__ __forceinline__ bool task_ready(const CholTask &c, const int32_t *fl, int look)
+{
+    auto ge = [&](int i, int v) { return __hip_atomic_load(fl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v; };
+    if (c.type == QT_ROW) return c.k == 0 || (ge(1 + c.k, c.k) && ge(1 + c.row, c.k));
+    if (c.type == QT_LOOK) return ge(1 + c.k, c.k - 1) && (c.k < 3 || ge(look, c.k - 1));
+    return c.k == 0 || (ge(1 + c.k, c.k) && (c.k < 2 || ge(look, c.k)));
+}
+__device__ __forceinline__ bool task_wait(const CholTask &c, const int32_t *fl, int look, const int32_t *err)
+{
+    if (c.type == QT_ROW) return c.k == 0 || (spin_until_ge(fl + 1 + c.k, c.k, err) && spin_until_ge(fl + 1 + c.row, c.k, err));
+    if (c.type == QT_LOOK) return spin_until_ge(fl + 1 + c.k, c.k - 1, err) && (c.k < 3 || spin_until_ge(fl + look, c.k - 1, err));
+    return c.k == 0 || (spin_until_ge(fl + 1 + c.k, c.k, err) && (c.k < 2 || spin_until_ge(fl + look, c.k, err)));
+}
+
+#ifndef PMK_Q_PLAIN
+#define PMK_Q_SC1 true
+#else
+#define PMK_Q_SC1 false
+#endif
+// block_row_update for the task queue: the deep product only needs block row k of L (and the task's own row) through
+// column k - 1, the block substitution needs the factorised diagonal tile k.  If tile k was already there when the task
+// started (`diag_ready`, the rule away from the end of a factorisation) its operands are staged first, under the
+// latency of the tile loads, exactly as in block_row_update; otherwise the product runs first -- beside the potrf
+// that some other workgroup is still busy with -- and wave 0 then waits for the tile (flag[0] >= k + 1), drops this
+// CU's L1 once more, and the operands are staged behind the product.  Returns false on a spin time-out (uniform).
+__device__ __forceinline__ bool block_row_update_queue(const PatchDesc &pd, real *__restrict__ S,
+                                                       const real *__restrict__ ninv_p, int k, int row, real *lds,
+                                                       bool diag_ready, const int32_t *fl, const int32_t *err)
+{
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t ld = pd.ld;
+    const int64_t c0 = (int64_t)k * TILE;
+    const int64_t r0 = (int64_t)row * TILE + 32 * wave;
+    const bool live = r0 < pd.n;
+    real *out = S + r0 + 2 * (lane & 15) + c0 * ld;
+    WaveTile<4, 1> acc;
+    if (live) {
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = tile_i(fi, lane, q);
+                const real2_t a = *reinterpret_cast<const real2_t *>(out + cl * ld);
+                acc.f[fi][0][q] = a[0];
+                acc.f[fi][1][q] = a[1];
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (diag_ready) stage_tri_operands(lds, S + c0 + c0 * ld, ld, ninv_p + (int64_t)k * (4 * SB * SB), tid, 256);
+    if (live) {
+#pragma unroll
+        for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc.f[fi][0][q] = -acc.f[fi][0][q];
+                acc.f[fi][1][q] = -acc.f[fi][1][q];
+            }
+        if (k > 0) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + c0, ld, S + r0, ld, k * TILE, lane);
+    }
+    bool ok = true;
+    if (!diag_ready) {
+        int *ctl = reinterpret_cast<int *>(lds);
+        if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+            if (tid == 0) {
+                const bool got = spin_until_ge(fl, k + 1, err);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ctl[2] = got ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        ok = __builtin_amdgcn_readfirstlane(ctl[2]) != 0;
+        __syncthreads();
+        if (ok) stage_tri_operands(lds, S + c0 + c0 * ld, ld, ninv_p + (int64_t)k * (4 * SB * SB), tid, 256);
+    }
+    __syncthreads();
+    if (!live || !ok) return ok;
+    tri_solve_inplace<1>(acc, lds, lane);
+#pragma unroll
+    for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cl = tile_i(fi, lane, q);
+            real2_t o;
+            o[0] = acc.f[fi][0][q];
+            o[1] = acc.f[fi][1][q];
+            put2<PMK_Q_SC1>(out + cl * ld, o);
+        }
+    return true;
+}
+
+__global__ __launch_bounds__(256, 2) void chol_queue_kernel(const PatchDesc *__restrict__ descs,
+                                                            const CholTask *__restrict__ tasks, QueueOffsets qo,
+                                                            int32_t *sched, int seg, int fstride, real *__restrict__ A,
+                                                            real *__restrict__ ninv, const real *__restrict__ y,
+                                                            real *__restrict__ z, int32_t *__restrict__ info,
+                                                            unsigned long long *__restrict__ clk)
+{
+    // all of the CU's LDS for two workgroups: the two control words of the task loop live in the staging array
+    // (consumed into registers, behind a barrier, before a task touches it)
+    __shared__ real lds[TRI_LDS_DOUBLES];
+    int *s_ctl = reinterpret_cast<int *>(lds);
+    const int tid = threadIdx.x;
+    // the scalar work of the loop (dequeue, polls, flags) belongs to wave 0: a uniform branch on the wave number and,
+    // inside it, a one-lane region that contains no barrier -- the loop itself stays a plain scalar loop
+    const bool wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    const bool probe = clk && blockIdx.x < 8 && tid == 0;
+    unsigned long long c0 = 0, r0 = 0;
+    if (probe) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    (void)hwid;
+    const int q = (int)(xcc & 7);
+    const int qbase = qo.off[q], nq = qo.off[q + 1] - qo.off[q];
+    int32_t *head = sched + SCHED_HEADS + 8 * seg + q, *err = sched + SCHED_ERR, *flags = sched + SCHED_FLAGS;
+    const int look = fstride - 1;      // index of a patch's look-ahead word among its flags
+    CholTask done = {0, 0, 0, -1, 0};     // the task this workgroup has just finished (its flags are raised at the loop head)
+    for (;;) {
+        if (wave0) {
+            if (tid == 0) {
+                if (done.type >= 0) {
+                    int32_t *fl = flags + (int64_t)done.pid * fstride;
+                    if (done.type == QT_ROW) __hip_atomic_store(fl + 1 + done.row, done.k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else if (done.type == QT_LOOK) __hip_atomic_store(fl + look, (int)done.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else __hip_atomic_store(fl, done.k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // Taking a task is one returning add on the head of this XCD's list.  The list is in an order in which
+                // everything a task waits for comes earlier, so whatever the wait below is for has been taken by a
+                // workgroup that is running: progress needs no assumption about dispatch order or residency.
+                int got = -1;
+                if (nq > 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    const int t = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t < nq) got = qbase + t;
+                }
+                int diag = 1;
+                if (got >= 0) {
+                    const CholTask c = tasks[got];
+                    const int32_t *fl = flags + (int64_t)c.pid * fstride;
+                    if (!task_wait(c, fl, look, err)) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        got = -1;
+                    } else if (c.type == QT_ROW) {
+                        diag = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= c.k + 1;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE L1 invalidate behind the matched polls
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                s_ctl[0] = got;
+                s_ctl[1] = diag;
+            }
+        }
+        __syncthreads();
+        const int gt = __builtin_amdgcn_readfirstlane(s_ctl[0]);
+        const int diag_ready = __builtin_amdgcn_readfirstlane(s_ctl[1]);
+        __syncthreads();                 // every wave has read the control words: the array is the task's now
+        if (gt < 0) break;
+        const CholTask tk = tasks[gt];
+#ifdef PMK_QTRACE
+        const int gtask = gt;
+        if (tid == 0 && gtask < QTRACE_MAX)
+            g_qtrace[QTRACE_WORDS * gtask + 3] = ((unsigned long long)hwid << 32) | ((unsigned)q << 28) | blockIdx.x;
+#endif
+        PMK_QSTAMP(0);
+        const PatchDesc pd = descs[tk.pid];
+        real *S = A + pd.aoff;
+        bool ok = true;
+        PMK_QSTAMP(1);
+#ifndef PMK_Q_NOCOMPUTE
+        if (tk.type == QT_ROW) {
+            ok = block_row_update_queue(pd, S, ninv + pd.ioff, tk.k, tk.row, lds, diag_ready != 0,
+                                        flags + (int64_t)tk.pid * fstride, err);
+        } else {
+            // LOOK (t): block columns 0 .. t - 2 onto diagonal tile t and its right-hand side; what is left of the right-hand
+            // side is parked in z_t (its final value comes from the potrf task).  POT (t >= 1): block column t - 1 (just
+            // finished by the ROW task of this block row) onto both, then the potrf; POT (0): the tile as K1 left it.
+            const int t = tk.k;
+            const int64_t t0 = (int64_t)t * TILE;
+            const bool pot = tk.type == QT_POT;
+            if (pot && t == 0) {
+                if (tid < TILE) lds[POTRF_RHS + tid] = y[pd.yoff + tid];
+            } else {
+                const bool from_z = pot && t >= 2;
+                lookahead_update<0, PMK_Q_SC1>(pd, S, (from_z ? z : const_cast<real *>(y)) + pd.yoff + t0, z + pd.yoff, t - 1, lds,
+                                               nullptr, 1, pot ? t - 1 : 0, pot ? t : t - 1, pot ? nullptr : z + pd.yoff + t0);
+            }
+            if (pot) {
+                workgroup_refresh();          // the tile went out write-through: re-read behind an L1 invalidate
+                tile_potrf<PMK_Q_SC1>(S + t0 + t0 * pd.ld, pd.ld, lds, ninv + pd.ioff + (int64_t)t * (4 * SB * SB),
+                                      z + pd.yoff + t0, info + tk.pid, t);
+            }
+        }
+        if (!ok) {
+            if (wave0) {
+                if (tid == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+        }
+#endif
+        // end of the task: every wave drains its stores and the workgroup meets; the flags go up at the loop head
+        drain_stores();
+        __syncthreads();
+        done = tk;
+        PMK_QSTAMP(2);
+    }
+    if (probe) {
+        clk[130 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - c0;
+        clk[130 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 }
 
@@ -792,6 +1154,123 @@ static int reserve_split(pmk_model *m, size_t partial_bytes, size_t solve_bytes)
     return 0;
 }
 
+// task lists of the queue path (see chol_queue_kernel), built once per model: list x serves the patch slots x, x + 8, ...
+// of `order` (sizes interleaved over the XCDs, all block rows of a patch on one XCD) in the order of the end-aligned step
+// schedule: for every step l the critical tasks first, then the block rows that are critical at step l + 1, then the
+// remaining block rows patch by patch (they stream the same block row k of L at the same time)
+static int build_queue(pmk_model *m)
+{
+    const int P = (int)m->P, max_nt = m->max_nt;
+    std::vector<CholTask> all;
+    int nseg = 1;
+    if (const char *e = std::getenv("PMK_QUEUE_SEGS")) nseg = std::max(1, std::min(QUEUE_MAX_SEGS, std::atoi(e)));
+    // the queue takes over at step L0 (the steps before it run as one launch each, launch_cholesky); negative: counted
+    // from the end
+    int L0 = m->queue_from;
+    if (L0 < 0) L0 = std::max(0, max_nt - 1 + L0);
+    L0 = std::min(L0, std::max(0, max_nt - 1));
+    m->queue_l0 = L0;
+    const int nsteps = max_nt - 1 - L0;
+    nseg = std::min(nseg, std::max(1, nsteps));
+    m->qsegs = nseg;
+    m->qoff.assign((size_t)nseg * 9, 0);
+    for (int sg = 0; sg < nseg; ++sg)
+        for (int x = 0; x < 8; ++x) {
+            const int l_lo = L0 + (int)((int64_t)nsteps * sg / nseg), l_hi = L0 + (int)((int64_t)nsteps * (sg + 1) / nseg);
+            auto col = [&](int pid, int l) { return l - (max_nt - m->desc[(size_t)pid].nt); };
+            auto nact = [&](int l) { return m->active_prefix[(size_t)std::min(max_nt + 1, max_nt - l)]; };
+            // ONE list per XCD is in use (list 2 x; list 2 x + 1 stays empty), in an order in which everything a task waits
+            // for comes earlier in the same list -- step by step: the block row the chain waits for (row k + 1), the
+            // look-ahead of the next diagonal tile, its potrf, the block row after that, then the rest patch by patch (they
+            // stream the same block row k of L at the same time).  A task is then only ever taken after everything it
+            // depends on has been taken, by a workgroup that is running: progress by construction.  (A chain list and a
+            // rows list per XCD, served by the two workgroups of a CU with opposite preference, pairs every potrf with a
+            // GEMM on its CU and was measured no faster; its take-before-ready protocol is not in the tree.)
+            std::vector<CholTask> cl;
+            if (sg == 0 && L0 == 0)
+                for (int s = x; s < P; s += 8) cl.push_back({m->order[(size_t)s], 0, 0, QT_POT, 0});
+            for (int l = l_lo; l < l_hi; ++l) {
+                const int G = max_nt - l - 1;
+                for (int s = x; s < nact(l); s += 8) {
+                    const int pid = m->order[(size_t)s], k = col(pid, l);
+                    cl.push_back({pid, (int16_t)k, (int16_t)(k + 1), QT_ROW, 0});
+                }
+                for (int s = x; s < nact(l); s += 8) {
+                    const int pid = m->order[(size_t)s], k = col(pid, l);
+                    if (k >= 1) cl.push_back({pid, (int16_t)(k + 1), (int16_t)(k + 1), QT_LOOK, 0});
+                }
+                for (int s = x; s < nact(l); s += 8) {
+                    const int pid = m->order[(size_t)s], k = col(pid, l);
+                    cl.push_back({pid, (int16_t)(k + 1), (int16_t)(k + 1), QT_POT, 0});
+                }
+                if (G >= 2)
+                    for (int s = x; s < nact(l); s += 8) {
+                        const int pid = m->order[(size_t)s], k = col(pid, l);
+                        cl.push_back({pid, (int16_t)k, (int16_t)(k + 2), QT_ROW, 0});
+                    }
+                for (int s = x; s < nact(l); s += 8) {
+                    const int pid = m->order[(size_t)s], k = col(pid, l);
+                    for (int bx = 2; bx < G; ++bx) cl.push_back({pid, (int16_t)k, (int16_t)(k + 1 + bx), QT_ROW, 0});
+                }
+            }
+            m->qoff[(size_t)sg * 9 + x] = (int32_t)all.size();
+            all.insert(all.end(), cl.begin(), cl.end());
+            m->qoff[(size_t)sg * 9 + x + 1] = (int32_t)all.size();
+        }
+    m->qfstride = (max_nt + 2 + 15) & ~15;       // diagonal count, one word per block row, the look-ahead word (last)
+    m->sched_bytes = sizeof(int32_t) * ((size_t)SCHED_FLAGS + (size_t)P * (size_t)m->qfstride);
+    // state of the flags when the queue takes over: a patch that is at column k0 of its own schedule at step L0 has its
+    // tiles 0 .. k0 factorised and every block row final through column k0 - 1 (k0 = 0: the first tile, chol_first_kernel)
+    std::vector<int32_t> init((size_t)SCHED_FLAGS + (size_t)P * (size_t)m->qfstride, 0);
+    if (L0 > 0)
+        for (int pid = 0; pid < P; ++pid) {
+            const int k0 = std::max(0, L0 - (max_nt - m->desc[(size_t)pid].nt));
+            int32_t *fl = init.data() + SCHED_FLAGS + (size_t)pid * (size_t)m->qfstride;
+            fl[0] = k0 + 1;
+            for (int i = 0; i < m->desc[(size_t)pid].nt; ++i) fl[1 + i] = k0;
+            fl[m->qfstride - 1] = k0;           // the look-ahead word: tiles <= k0 need none any more
+        }
+    PMK_HIP(hipMalloc(&m->d_qtasks, sizeof(CholTask) * std::max<size_t>(all.size(), 1)));
+    PMK_HIP(hipMalloc((void **)&m->d_sched, m->sched_bytes));
+    PMK_HIP(hipMalloc((void **)&m->d_sched_init, m->sched_bytes));
+    PMK_HIP(hipMemcpy(m->d_sched_init, init.data(), m->sched_bytes, hipMemcpyHostToDevice));
+    PMK_HIP(hipMemcpy(m->d_qtasks, all.data(), sizeof(CholTask) * all.size(), hipMemcpyHostToDevice));
+    m->queue_built = true;
+    return 0;
+}
+
+static int launch_cholesky_queue(pmk_model *m, hipStream_t s)
+{
+    pmk_ctx *c = m->ctx;
+    PMK_HIP(hipMemcpyAsync(m->d_sched, m->d_sched_init, m->sched_bytes, hipMemcpyDeviceToDevice, s));
+    const bool fine = c->timers >= 2;
+    for (int sg = 0; sg < m->qsegs; ++sg) {
+        const int evi = m->queue_l0 + sg;
+        if (fine) {
+            while ((int)c->panel_ev.size() <= evi) {
+                hipEvent_t a, b;
+                PMK_HIP(hipEventCreate(&a));
+                PMK_HIP(hipEventCreate(&b));
+                c->panel_ev.push_back({a, b});
+            }
+            PMK_HIP(hipEventRecord(c->panel_ev[(size_t)evi].first, s));
+        }
+        QueueOffsets qo;
+        for (int x = 0; x < 9; ++x) qo.off[x] = m->qoff[(size_t)sg * 9 + x];
+        const unsigned grid = (unsigned)std::min<int64_t>(2 * (int64_t)c->num_cu, std::max<int64_t>(8, qo.off[8] - qo.off[0]));
+        hipLaunchKernelGGL(chol_queue_kernel, dim3(grid), dim3(256), 0, s, m->d_desc, (const CholTask *)m->d_qtasks, qo,
+                           m->d_sched, sg, m->qfstride, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y,
+                           (real *)m->d_z, m->d_info, sg == 0 && m->queue_l0 == 0 ? m->ctx->d_clk : nullptr);
+        if (fine) {
+            PMK_HIP(hipEventRecord(c->panel_ev[(size_t)evi].second, s));
+            c->panel_n = evi + 1;
+        }
+    }
+    PMK_HIP(hipGetLastError());
+    m->queue_used = true;
+    return 0;
+}
+
 // col_ev (may be null): event s of the pipelined kernel-matrix build = "stage s is in the slabs"; launch l reads block
 // columns that stages <= l + 1 produced (pmk_kmat.hip), the first kernel reads stage 0
 int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const hipEvent_t *col_ev, int n_ev)
@@ -805,6 +1284,15 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
         PMK_HIP(hipMemsetAsync(m->ctx->d_clk + 130 * x, 0, sizeof(unsigned long long) * 128, s));
     pmk_ctx *c = m->ctx;
     c->panel_n = 0;
+    m->queue_used = false;
+    // the task queue takes the steps from m->queue_l0 on (0: all of them, and the first tiles too)
+    int l_end = m->max_nt - 1;
+    if (m->queue_mode && !m->split_mode && !col_ev) {
+        if (!m->queue_built)
+            if (int rc = build_queue(m)) return rc;
+        l_end = m->queue_l0;
+        if (l_end == 0) return launch_cholesky_queue(m, s);
+    }
     const bool fine = c->timers >= 2;
     const int want_wg = 2 * c->num_cu;                     // workgroups that fill the chip (two per CU)
     auto ev_begin = [&](int l) -> int {
@@ -828,7 +1316,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
     if (col_ev && n_ev > 0) PMK_HIP(hipStreamWaitEvent(s, col_ev[0], 0));
     hipLaunchKernelGGL(chol_first_kernel, dim3((unsigned)np), dim3(256), 0, s, m->d_desc, (real *)m->d_a, (real *)m->d_inv,
                        (const real *)m->d_y, (real *)m->d_z, m->d_info);
-    for (int l = l0; l + 1 < m->max_nt; ++l) {
+    for (int l = l0; l < l_end; ++l) {
         // patch p runs block column k = l - (max_nt - nt_p) at launch l (end-aligned); it takes part from k = l0 on:
         // nt_p >= max_nt - l + l0.  Those patches are a prefix of `order` (sorted by nt, largest first).
         const int nactive = m->active_prefix[(size_t)std::min(m->max_nt + 1, m->max_nt - l + l0)];
@@ -861,6 +1349,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
         if (int rc = ev_end(l)) return rc;
     }
     PMK_HIP(hipGetLastError());
+    if (l_end < m->max_nt - 1) return launch_cholesky_queue(m, s);
     return 0;
 }
 
@@ -896,6 +1385,18 @@ static int launch_split_solves(pmk_model *m, hipStream_t s)
     PMK_HIP(hipGetLastError());
     return 0;
 }
+
+#if defined(PMK_QTRACE) && !defined(PMK_REAL_F32)
+// diagnostic build only: the per-task stamps of the last queue launch and its task list (pid, k, row, type per task)
+extern "C" int pmk_qtrace_dump(pmk_model *m, unsigned long long *stamps, int32_t *tasks, int ntasks_max, int32_t *qoff)
+{
+    const int nt = std::min(std::min(ntasks_max, (int)m->qoff.back()), QTRACE_MAX);
+    for (int x = 0; x < 9; ++x) qoff[x] = m->qoff[(size_t)x];
+    if (hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_qtrace), sizeof(unsigned long long) * QTRACE_WORDS * (size_t)nt) != hipSuccess) return -1;
+    if (hipMemcpy(tasks, m->d_qtasks, sizeof(CholTask) * (size_t)nt, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return nt;
+}
+#endif
 
 #if defined(PMK_TRACE) && !defined(PMK_REAL_F32)
 extern "C" int pmk_trace_dump(unsigned long long *out, int nwords)

@@ -105,6 +105,17 @@ struct pmk_model {
     // split path (few, large patches: the deep products of a step are cut along K over several workgroups and the two
     // triangular solves run block by block over many workgroups): chosen at creation from P and the tile counts
     bool split_mode = false;
+    // task-queue form of the batched factorisation (one launch for all block columns, pmk_chol.hip): per-XCD task lists
+    // and the scheduling block (list heads, error word, per-patch dependency flags), built at the first fit
+    std::vector<int32_t> order;         // host copy of d_order
+    int queue_mode = 0;                 // 1: task-queue factorisation (PMK_CHOL_QUEUE=1; measured slower than one launch per block column)
+    bool queue_built = false, queue_used = false;
+    void *d_qtasks = nullptr;
+    int qsegs = 1;                      // launches the lists are cut into (1 unless PMK_QUEUE_SEGS says otherwise)
+    std::vector<int32_t> qoff;          // [segment][9]: list of XCD x in a segment = tasks[qoff[x] .. qoff[x + 1])
+    int32_t *d_sched = nullptr, *d_sched_init = nullptr; size_t sched_bytes = 0;
+    int queue_from = 0, queue_l0 = 0;   // first step the queue takes (PMK_QUEUE_FROM; negative: counted from the end)
+    int qfstride = 0;
     void *d_partial = nullptr; size_t partial_bytes = 0;      // partial product tiles of one step
     void *d_solve_part = nullptr; size_t solve_bytes = 0;     // partial matrix-vector products of one solve block
     int64_t tot_a = 0, tot_x = 0, tot_y = 0, tot_inv = 0;

@@ -1153,3 +1153,29 @@ def test_plan_kernel_in_both_dot_modes_vs_oracle(D, dot_mode):
         assert np.array_equal(dbg["item_t"][s][:-1], ts[keep])
     host_home = [pmk.findpartition(x, root) for x in Xq[:500]]
     assert np.array_equal(host_home, dbg["home"][:500])
+
+
+def test_task_queue_factorisation_is_bit_identical_to_the_step_launches(monkeypatch):
+    # the opt-in one-launch form of the factorisation (pmk_chol.hip, chol_queue_kernel; PMK_CHOL_QUEUE=1) against the
+    # default one-launch-per-block-column form: ragged sizes (end-aligned schedule, single-tile patches), same bits in
+    # L, the inverted diagonal blocks, z and c -- also when the queue only takes over for the last steps
+    rng = np.random.default_rng(77)
+    sizes = [1, 130, 257, 300, 640, 1000, 1111, 1500, 97, 128, 900, 513]
+    Xs = [rng.uniform(-4, 4, (n, 2)) for n in sizes]
+    ys = [np.sin(x[:, 0]) * np.cos(0.5 * x[:, 1]) for x in Xs]
+    th = pmk.Spline34KernelType(1 / 3.0)
+    ref = None
+    for queue, frm in (("0", "0"), ("1", "0"), ("1", "-3"), ("1", "5")):
+        monkeypatch.setenv("PMK_CHOL_QUEUE", queue)
+        monkeypatch.setenv("PMK_QUEUE_FROM", frm)
+        model, cs, info = pmk.fit_patches(Xs, ys, th, 1e-5)
+        assert np.all(info == 0)
+        for _ in range(3):                      # the scheduling state is rebuilt by every fit
+            model.fit(th, 1e-5)
+        assert np.all(model.info() == 0)
+        got = [(model.get(r, M.GET_C), model.get(r, M.GET_L), model.get(r, M.GET_LINV_DIAG)) for r in range(len(sizes))]
+        if ref is None:
+            ref = got
+            continue
+        for (c0, L0, N0), (c1, L1, N1) in zip(ref, got):
+            assert np.array_equal(c0, c1) and np.array_equal(L0, L1) and np.array_equal(N0, N1)
