@@ -71,8 +71,12 @@ const char *pmk_last_error(void);
 
 /* ---- context ------------------------------------------------------------------------- */
 int  pmk_ctx_create(int device, pmk_ctx **out);
-/* launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL -> context's own */
+/* launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL -> context's own (a non-blocking stream:
+ * NOT ordered with the device's default stream) */
 int  pmk_ctx_set_stream(pmk_ctx *ctx, void *hip_stream);
+/* launch on the device's legacy default (null) stream -- the stream a framework's "default stream" is: the handle of that
+ * stream is 0, which pmk_ctx_set_stream reads as "the context's own" */
+int  pmk_ctx_set_stream_null(pmk_ctx *ctx);
 /* on = 1: pmk_model_fit builds the kernel matrix block column by block column on a low-priority side stream while the
  * factorisation's launches run (results are bit-identical either way).  Default 0 = build it first, on the context's
  * stream: on MI355X the overlap measured 0.3 ms slower per 256 x 2000 fit (the step launches leave no room).  Never
@@ -232,6 +236,14 @@ int  pmk_shard_segments(const int64_t *region_offsets, int64_t P_global, int wor
  * stream after the plan; results with pmk_query_fetch.  total_items (may be NULL): this rank's item count. */
 int  pmk_query_predict_sharded(pmk_query *q, pmk_comm *comm, const pmk_kernel_desc *th,
                                const pmk_kernel_desc *weight_th, double radius, double delta, int64_t *total_items);
+/* the same step with REPLICATED queries (every rank passes all queries): plan of all queries -> queryinner! for the items
+ * in this rank's leaves -> one ncclAllGather of padded (u, v) slices (every rank knows every slice's size from its own
+ * plan) -> mixture of all queries on every rank.  BASELINE.json's "RCCL all-gather ... of the per-patch predictions before
+ * the mixture weights are applied", literally; collective. */
+int  pmk_query_predict_allgather(pmk_query *q, pmk_comm *comm, const pmk_kernel_desc *th,
+                                 const pmk_kernel_desc *weight_th, double radius, double delta, int64_t *total_items);
+/* payload bytes this rank sent / received in the exchange of its last predict step (either form) */
+int  pmk_comm_last_bytes(const pmk_comm *comm, int64_t *sent, int64_t *received);
 /* stage 3: mixture weights and blend (mixtureGP.jl:224-272) for queries [q0, q1).  Enqueues. */
 int  pmk_query_mix(pmk_query *q, const pmk_kernel_desc *weight_th, int64_t q0, int64_t q1);
 /* blocks; Yq, Vq [Nq] (either may be NULL) */

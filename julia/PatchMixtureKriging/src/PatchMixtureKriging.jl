@@ -476,6 +476,29 @@ function querymixtureGP!(Yq::Vector{T}, Vq::Vector{T}, Xq::Vector{Vector{T}}, η
     return nothing
 end
 
+"""querymixtureGP_allgather!(Yq, Vq, Xq_all, η_local, comm, root, levels, radius, δ, θ, σ², weight_θ): the replicated-query form
+of the sharded predict step (pmk_query_predict_allgather): every rank passes ALL queries, evaluates the items of its own
+leaves, one RCCL all-gather of the (u, v) slices, and every rank ends with all of Yq, Vq."""
+function querymixtureGP_allgather!(Yq::Vector{T}, Vq::Vector{T}, Xq::Vector{Vector{T}}, η::MixtureGPType{T}, comm::Comm, root, levels,
+                                   radius::T, δ::T, θ, σ², weight_θ)::Nothing where T
+    η.model == C_NULL && throw(PMKError("fitmixtureGP! must run before querymixtureGP_allgather!"))
+    Nq = length(Xq); Xm = pack(Xq)
+    resize!(Yq, Nq); resize!(Vq, Nq)
+    P = Int(ccall((:pmk_model_num_patches, libpmk), Int64, (Ptr{Cvoid},), η.model))
+    check(ccall((:pmk_model_set_bsp, libpmk), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), η.model, native(root), comm.rank * P), "pmk_model_set_bsp")
+    q = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pmk_query_create, libpmk), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ref{Ptr{Cvoid}}), η.model, Nq, Xm, q), "pmk_query_create")
+    try
+        check(ccall((:pmk_query_predict_allgather, libpmk), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ref{KernelDesc}, Ref{KernelDesc}, Float64, Float64, Ptr{Int64}),
+            q[], comm.h, Ref(desc(θ)), Ref(desc(weight_θ)), radius, δ, C_NULL), "pmk_query_predict_allgather")
+        check(ccall((:pmk_query_fetch, libpmk), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), q[], Yq, Vq), "pmk_query_fetch")
+    finally
+        ccall((:pmk_query_destroy, libpmk), Cvoid, (Ptr{Cvoid},), q[])
+    end
+    return nothing
+end
+
 function querymixtureGP(Xq::Vector{Vector{T}}, η::MixtureGPType{T}, root, levels, radius::T, δ::T, θ, σ², weight_θ;
                         debug_flag = false) where T
     Yq = Vector{T}(undef, 0); Vq = Vector{T}(undef, 0)

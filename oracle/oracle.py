@@ -33,6 +33,8 @@ def kernel(family, *params, flags=0):
 
 
 def build(force=False):
+    if os.environ.get("PMK_ORACLE_LIB"):          # e.g. the sanitizer build (make -C oracle asan; tools/run_asan.sh)
+        return os.environ["PMK_ORACLE_LIB"]
     so = os.path.join(_HERE, "libpmk_oracle.so")
     src = os.path.join(_HERE, "pmk_oracle.c")
     if force or not os.path.exists(so) or (

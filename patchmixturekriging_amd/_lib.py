@@ -51,6 +51,7 @@ SIGNATURES = {
     "pmk_last_error": (C.c_char_p, []),
     "pmk_ctx_create": (C.c_int, [C.c_int, _vpp]),
     "pmk_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "pmk_ctx_set_stream_null": (C.c_int, [_vp]),
     "pmk_ctx_synchronize": (C.c_int, [_vp]),
     "pmk_ctx_destroy": (None, [_vp]),
     "pmk_ctx_enable_timers": (C.c_int, [_vp, C.c_int]),
@@ -103,6 +104,8 @@ SIGNATURES = {
     "pmk_comm_destroy": (None, [_vp]),
     "pmk_shard_segments": (C.c_int, [_ip, C.c_int64, C.c_int, _ip, _ip]),
     "pmk_query_predict_sharded": (C.c_int, [_vp, _vp, _kp, _kp, C.c_double, C.c_double, _ip]),
+    "pmk_query_predict_allgather": (C.c_int, [_vp, _vp, _kp, _kp, C.c_double, C.c_double, _ip]),
+    "pmk_comm_last_bytes": (C.c_int, [_vp, _ip, _ip]),
     "pmk_query_fetch": (C.c_int, [_vp, _dp, _dp]),
     "pmk_query_debug": (C.c_int, [_vp, _ip, _ip, _ip, _dp, _dp, _dp, _dp]),
     "pmk_query_destroy": (None, [_vp]),

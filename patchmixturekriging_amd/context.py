@@ -16,7 +16,12 @@ class Context:
         self.device = device
 
     def set_stream(self, stream_ptr):
+        """launch on a caller-owned stream; 0 / None = the context's own (non-blocking) stream"""
         _lib.check(self.L.pmk_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)), "pmk_ctx_set_stream")
+
+    def set_stream_null(self):
+        """launch on the device's legacy default stream (handle 0: what a framework's default stream is)"""
+        _lib.check(self.L.pmk_ctx_set_stream_null(self.h), "pmk_ctx_set_stream_null")
 
     def synchronize(self):
         _lib.check(self.L.pmk_ctx_synchronize(self.h), "pmk_ctx_synchronize")
@@ -67,6 +72,12 @@ class Comm:
         buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
         _lib.check(ctx.L.pmk_comm_create(ctx.h, self.rank, self.world, buf, C.byref(h)), "pmk_comm_create")
         self.h = h
+
+    def last_bytes(self):
+        """payload bytes this rank (sent, received) in the exchange of its last predict step"""
+        a, b = C.c_int64(), C.c_int64()
+        _lib.check(self.ctx.L.pmk_comm_last_bytes(self.h, C.byref(a), C.byref(b)), "pmk_comm_last_bytes")
+        return a.value, b.value
 
     def close(self):
         if getattr(self, "h", None):

@@ -165,7 +165,7 @@ int pmk_ctx_create(int device, pmk_ctx **out)
         hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&c->fit_begin, hipEventDisableTiming) != hipSuccess) {
         set_error("pmk_ctx_create: device %d: %s", device, hipGetErrorString(hipGetLastError()));
-        delete c;
+        pmk_ctx_destroy(c);                 // releases whichever of the streams / events were created
         return -100;
     }
     c->num_cu = prop.multiProcessorCount;
@@ -190,6 +190,13 @@ int pmk_ctx_set_stream(pmk_ctx *ctx, void *hip_stream)
 {
     if (!ctx) { set_error("pmk_ctx_set_stream: ctx is NULL"); return -1; }
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return 0;
+}
+
+int pmk_ctx_set_stream_null(pmk_ctx *ctx)
+{
+    if (!ctx) { set_error("pmk_ctx_set_stream_null: ctx is NULL"); return -1; }
+    ctx->stream = nullptr;               // the device's legacy default stream
     return 0;
 }
 

@@ -61,7 +61,10 @@ bool rccl_load()
             r.AllGather && r.GetErrorString)
             g_rccl = r;
     });
-    if (!g_rccl.lib) pmk::set_error("RCCL is not available (librccl.so.1 could not be loaded: %s)", dlerror() ? dlerror() : "?");
+    if (!g_rccl.lib) {
+        const char *why = dlerror();          // one call: it clears the message
+        pmk::set_error("RCCL is not available (librccl.so.1 could not be loaded, or lacks an entry point: %s)", why ? why : "?");
+    }
     return g_rccl.lib != nullptr;
 }
 
@@ -80,6 +83,9 @@ struct pmk_comm {
     int force_exchange = 0;               // tests: run the exchange (self sends through RCCL) even at world == 1
     pmk_query *remote = nullptr;          // the received requests, as a query object that is reloaded every step
     pmk_model *remote_model = nullptr;
+    int64_t remote_P = 0; int remote_D = 0;   // tree / dimension the remote query was created for (its buffers are sized by them)
+    double *d_ag = nullptr; int64_t ag_cap = 0;   // all-gather variant: [2][maxc] out + [world][2][maxc] in
+    int64_t bytes_sent = 0, bytes_recv = 0;   // payload of the last predict step's exchange (this rank)
 };
 
 #define PMK_NCCL(expr)                                                                               \
@@ -87,6 +93,17 @@ struct pmk_comm {
         ncclResult_t r__ = (expr);                                                                   \
         if (r__ != 0) {                                                                              \
             pmk::set_error("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__, g_rccl.GetErrorString(r__)); \
+            return -101;                                                                             \
+        }                                                                                            \
+    } while (0)
+
+// inside ncclGroupStart / ncclGroupEnd: a failing call must not leave the group open
+#define PMK_NCCL_IN_GROUP(expr)                                                                      \
+    do {                                                                                             \
+        ncclResult_t r__ = (expr);                                                                   \
+        if (r__ != 0) {                                                                              \
+            pmk::set_error("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__, g_rccl.GetErrorString(r__)); \
+            (void)g_rccl.GroupEnd();                                                                 \
             return -101;                                                                             \
         }                                                                                            \
     } while (0)
@@ -125,7 +142,7 @@ int pmk_comm_create(pmk_ctx *ctx, int rank, int world, const void *id, pmk_comm 
         delete c;
         return -101;
     }
-    if (hipMalloc((void **)&c->d_counts, sizeof(int64_t) * (size_t)(world + world * world)) != hipSuccess) {
+    if (hipMalloc((void **)&c->d_counts, sizeof(int64_t) * (size_t)(2 * (world + 1) + world * (world + 1))) != hipSuccess) {
         set_error("pmk_comm_create: out of device memory");
         g_rccl.CommDestroy(c->comm);
         delete c;
@@ -140,7 +157,7 @@ void pmk_comm_destroy(pmk_comm *c)
     if (!c) return;
     if (c->remote) pmk_query_destroy(c->remote);
     for (void *p : {(void *)c->d_counts, (void *)c->d_xs, (void *)c->d_rx, (void *)c->d_ru, (void *)c->d_rv, (void *)c->d_rg,
-                    (void *)c->d_rr})
+                    (void *)c->d_rr, (void *)c->d_ag})
         if (p) (void)hipFree(p);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     delete c;
@@ -221,54 +238,84 @@ int pmk_query_predict_sharded(pmk_query *q, pmk_comm *c, const pmk_kernel_desc *
                   (long long)m->leaf_base, (long long)(m->leaf_base + m->P));
         return -3;
     }
+    // The call is collective: a rank that fails locally must not leave its peers inside a send / receive.  Every
+    // fallible local step comes before a collective, and its status travels with the next all-gather so that all ranks
+    // give up together: (1) the plan, with the segment table; (2) the buffers, in a second (W words) all-gather.
     int rc = pmk_query_plan(q, radius, delta);
-    if (rc) return rc;
-    if (total_items) *total_items = q->total;
+    if (!rc && total_items) *total_items = q->total;
+    c->bytes_sent = c->bytes_recv = 0;
     if (W == 1 && !c->force_exchange) {
+        if (rc) return rc;
         if ((rc = pmk_query_items(q, th))) return rc;
         return pmk_query_mix(q, weight_th, 0, q->Nq);
     }
     PMK_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    std::vector<int64_t> sfirst((size_t)W), scount((size_t)W), table((size_t)(W * W));
-    if ((rc = pmk_shard_segments(q->roff.data(), m->P_global, W, sfirst.data(), scount.data()))) return rc;
-    // every rank's segment sizes to every rank (W x W table, a few hundred bytes)
-    PMK_HIP(hipMemcpyAsync(c->d_counts, scount.data(), sizeof(int64_t) * (size_t)W, hipMemcpyHostToDevice, s));
-    PMK_NCCL(g_rccl.AllGather(c->d_counts, c->d_counts + W, (size_t)W, ncclInt64, c->comm, s));
-    PMK_HIP(hipMemcpyAsync(table.data(), c->d_counts + W, sizeof(int64_t) * (size_t)(W * W), hipMemcpyDeviceToHost, s));
+    const int W1 = W + 1;                               // a row of the table: W segment sizes + the rank's status
+    std::vector<int64_t> sfirst((size_t)W, 0), row((size_t)W1, 0), table((size_t)(W * W1));
+    if (!rc) rc = pmk_shard_segments(q->roff.data(), m->P_global, W, sfirst.data(), row.data());
+    row[(size_t)W] = rc;
+    int64_t *d_row = c->d_counts, *d_table = c->d_counts + 2 * W1;
+    PMK_HIP(hipMemcpyAsync(d_row, row.data(), sizeof(int64_t) * (size_t)W1, hipMemcpyHostToDevice, s));
+    PMK_NCCL(g_rccl.AllGather(d_row, d_table, (size_t)W1, ncclInt64, c->comm, s));
+    PMK_HIP(hipMemcpyAsync(table.data(), d_table, sizeof(int64_t) * (size_t)(W * W1), hipMemcpyDeviceToHost, s));
     PMK_HIP(hipStreamSynchronize(s));
+    for (int r = 0; r < W; ++r)
+        if (table[(size_t)(r * W1 + W)] != 0) {
+            if (!rc) { set_error("pmk_query_predict_sharded: rank %d failed in its plan (%lld)", r, (long long)table[(size_t)(r * W1 + W)]); rc = -6; }
+            return rc;
+        }
+    const std::vector<int64_t> &scount = row;
     std::vector<int64_t> rcount((size_t)W), rfirst((size_t)W);
     int64_t nrecv = 0;
     for (int r = 0; r < W; ++r) {
-        rcount[(size_t)r] = table[(size_t)(r * W + c->rank)];      // what rank r asks of me
+        rcount[(size_t)r] = table[(size_t)(r * W1 + c->rank)];      // what rank r asks of me
         rfirst[(size_t)r] = nrecv;
         nrecv += rcount[(size_t)r];
     }
-    if (nrecv > 0x7fffffff) { set_error("pmk_query_predict_sharded: too many requests (%lld)", (long long)nrecv); return -5; }
-    if ((rc = comm_reserve(c, m->D, q->total, nrecv))) return rc;
+    // buffers and the query object of the received requests (recreated when the tree or the dimension changed: its
+    // region-offset array is sized by the tree it was created for)
+    if (nrecv > 0x7fffffff) { set_error("pmk_query_predict_sharded: too many requests (%lld)", (long long)nrecv); rc = -5; }
+    if (!rc) rc = comm_reserve(c, m->D, q->total, nrecv);
+    if (!rc && (!c->remote || c->remote_model != m || c->remote_P != m->P_global || c->remote_D != m->D)) {
+        if (c->remote) pmk_query_destroy(c->remote);
+        c->remote = nullptr;
+        rc = pmk_query_create(m, 0, nullptr, &c->remote);
+        c->remote_model = m; c->remote_P = m->P_global; c->remote_D = m->D;
+    }
+    {
+        int64_t st = rc, *d_st = c->d_counts + W1;              // second agreement: W status words
+        std::vector<int64_t> all((size_t)W, 0);
+        PMK_HIP(hipMemcpyAsync(d_st, &st, sizeof(int64_t), hipMemcpyHostToDevice, s));
+        PMK_NCCL(g_rccl.AllGather(d_st, d_table, 1, ncclInt64, c->comm, s));
+        PMK_HIP(hipMemcpyAsync(all.data(), d_table, sizeof(int64_t) * (size_t)W, hipMemcpyDeviceToHost, s));
+        PMK_HIP(hipStreamSynchronize(s));
+        for (int r = 0; r < W; ++r)
+            if (all[(size_t)r] != 0) {
+                if (!rc) { set_error("pmk_query_predict_sharded: rank %d could not set up its buffers (%lld)", r, (long long)all[(size_t)r]); rc = -6; }
+                return rc;
+            }
+    }
     const int D = m->D;
     // 1. requests out, requests in
     if (q->total > 0 && (rc = launch_export_requests(q, 0, q->total, c->d_xs, c->d_rg, s))) return rc;
     PMK_NCCL(g_rccl.GroupStart());
     for (int r = 0; r < W; ++r) {
         if (scount[(size_t)r] > 0) {
-            PMK_NCCL(g_rccl.Send(c->d_xs + sfirst[(size_t)r] * D, (size_t)(scount[(size_t)r] * D), ncclFloat64, r, c->comm, s));
-            PMK_NCCL(g_rccl.Send(c->d_rg + sfirst[(size_t)r], (size_t)scount[(size_t)r], ncclInt32, r, c->comm, s));
+            PMK_NCCL_IN_GROUP(g_rccl.Send(c->d_xs + sfirst[(size_t)r] * D, (size_t)(scount[(size_t)r] * D), ncclFloat64, r, c->comm, s));
+            PMK_NCCL_IN_GROUP(g_rccl.Send(c->d_rg + sfirst[(size_t)r], (size_t)scount[(size_t)r], ncclInt32, r, c->comm, s));
         }
         if (rcount[(size_t)r] > 0) {
-            PMK_NCCL(g_rccl.Recv(c->d_rx + rfirst[(size_t)r] * D, (size_t)(rcount[(size_t)r] * D), ncclFloat64, r, c->comm, s));
-            PMK_NCCL(g_rccl.Recv(c->d_rr + rfirst[(size_t)r], (size_t)rcount[(size_t)r], ncclInt32, r, c->comm, s));
+            PMK_NCCL_IN_GROUP(g_rccl.Recv(c->d_rx + rfirst[(size_t)r] * D, (size_t)(rcount[(size_t)r] * D), ncclFloat64, r, c->comm, s));
+            PMK_NCCL_IN_GROUP(g_rccl.Recv(c->d_rr + rfirst[(size_t)r], (size_t)rcount[(size_t)r], ncclInt32, r, c->comm, s));
+        }
+        if (r != c->rank) {
+            c->bytes_sent += scount[(size_t)r] * (8 * D + 4) + rcount[(size_t)r] * 16;
+            c->bytes_recv += rcount[(size_t)r] * (8 * D + 4) + scount[(size_t)r] * 16;
         }
     }
     PMK_NCCL(g_rccl.GroupEnd());
     // 2. queryinner! for everything received
-    if (!c->remote || c->remote_model != m) {
-        if (c->remote) pmk_query_destroy(c->remote);
-        c->remote = nullptr;
-        if ((rc = pmk_query_create(m, 0, nullptr, &c->remote))) return rc;
-        c->remote_model = m;
-    }
-    c->remote->roff_P = m->P_global;
     if ((rc = query_set_items(c->remote, nrecv, c->d_rx, c->d_rr))) return rc;
     if ((rc = pmk_query_items(c->remote, th))) return rc;
     if (nrecv > 0 && (rc = launch_export_results(c->remote, c->d_ru, c->d_rv, s))) return rc;
@@ -276,17 +323,84 @@ int pmk_query_predict_sharded(pmk_query *q, pmk_comm *c, const pmk_kernel_desc *
     PMK_NCCL(g_rccl.GroupStart());
     for (int r = 0; r < W; ++r) {
         if (rcount[(size_t)r] > 0) {
-            PMK_NCCL(g_rccl.Send(c->d_ru + rfirst[(size_t)r], (size_t)rcount[(size_t)r], ncclFloat64, r, c->comm, s));
-            PMK_NCCL(g_rccl.Send(c->d_rv + rfirst[(size_t)r], (size_t)rcount[(size_t)r], ncclFloat64, r, c->comm, s));
+            PMK_NCCL_IN_GROUP(g_rccl.Send(c->d_ru + rfirst[(size_t)r], (size_t)rcount[(size_t)r], ncclFloat64, r, c->comm, s));
+            PMK_NCCL_IN_GROUP(g_rccl.Send(c->d_rv + rfirst[(size_t)r], (size_t)rcount[(size_t)r], ncclFloat64, r, c->comm, s));
         }
         if (scount[(size_t)r] > 0) {
-            PMK_NCCL(g_rccl.Recv(q->d_u + sfirst[(size_t)r], (size_t)scount[(size_t)r], ncclFloat64, r, c->comm, s));
-            PMK_NCCL(g_rccl.Recv(q->d_v + sfirst[(size_t)r], (size_t)scount[(size_t)r], ncclFloat64, r, c->comm, s));
+            PMK_NCCL_IN_GROUP(g_rccl.Recv(q->d_u + sfirst[(size_t)r], (size_t)scount[(size_t)r], ncclFloat64, r, c->comm, s));
+            PMK_NCCL_IN_GROUP(g_rccl.Recv(q->d_v + sfirst[(size_t)r], (size_t)scount[(size_t)r], ncclFloat64, r, c->comm, s));
         }
     }
     PMK_NCCL(g_rccl.GroupEnd());
     // 4. blend
     return pmk_query_mix(q, weight_th, 0, q->Nq);
+}
+
+// The north star's literal form of the same step: the QUERIES ARE REPLICATED (every rank passes all of them and plans all
+// of them against the global tree), every rank evaluates queryinner! for the items that fall into ITS leaves, and ONE
+// ncclAllGather of equal, padded (u, v) slices -- every rank knows every segment's size from its own plan, so no table
+// is exchanged -- completes every rank's item buffers before the mixture weights are applied to all queries.
+// Against the request / response form above: no point travels, every (u, v) travels to every rank ((W - 1) x 16 B per
+// item in, against 36 B per item that crosses ranks), and the plan is W times larger per rank.
+int pmk_query_predict_allgather(pmk_query *q, pmk_comm *c, const pmk_kernel_desc *th, const pmk_kernel_desc *weight_th,
+                                double radius, double delta, int64_t *total_items)
+{
+    if (!q || !c) { set_error("pmk_query_predict_allgather: NULL argument"); return -1; }
+    pmk_model *m = q->m;
+    pmk_ctx *ctx = m->ctx;
+    if (ctx != c->ctx) { set_error("pmk_query_predict_allgather: the query's model lives on another context"); return -2; }
+    const int W = c->world;
+    if (m->P * W != m->P_global || m->leaf_base != (int64_t)c->rank * m->P) {
+        set_error("pmk_query_predict_allgather: rank %d of %d holds the leaves [%lld, %lld) of %lld", c->rank, W,
+                  (long long)m->leaf_base, (long long)(m->leaf_base + m->P), (long long)m->P_global);
+        return -3;
+    }
+    // the plan is a function of (queries, tree) alone: identical on every rank, so a failure is one on every rank
+    int rc = pmk_query_plan(q, radius, delta);
+    if (rc) return rc;
+    if (total_items) *total_items = q->total;
+    c->bytes_sent = c->bytes_recv = 0;
+    if ((rc = pmk_query_items(q, th))) return rc;                 // the items of this rank's leaves
+    if (W > 1 || c->force_exchange) {
+        PMK_HIP(hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        std::vector<int64_t> sfirst((size_t)W), scount((size_t)W);
+        if ((rc = pmk_shard_segments(q->roff.data(), m->P_global, W, sfirst.data(), scount.data()))) return rc;
+        const int64_t maxc = std::max<int64_t>(1, *std::max_element(scount.begin(), scount.end()));
+        if ((int64_t)(W + 1) * 2 * maxc > c->ag_cap) {           // deterministic in the plan: every rank grows alike
+            if (c->d_ag) (void)hipFree(c->d_ag);
+            c->d_ag = nullptr; c->ag_cap = 0;
+            const int64_t cap = (int64_t)(W + 1) * 2 * (maxc + maxc / 8);
+            PMK_HIP(hipMalloc((void **)&c->d_ag, sizeof(double) * (size_t)cap));
+            c->ag_cap = cap;
+        }
+        double *out = c->d_ag, *in = c->d_ag + 2 * maxc;
+        const int64_t mine = scount[(size_t)c->rank];
+        if (mine > 0) {
+            PMK_HIP(hipMemcpyAsync(out, q->d_u + sfirst[(size_t)c->rank], sizeof(double) * (size_t)mine, hipMemcpyDeviceToDevice, s));
+            PMK_HIP(hipMemcpyAsync(out + maxc, q->d_v + sfirst[(size_t)c->rank], sizeof(double) * (size_t)mine, hipMemcpyDeviceToDevice, s));
+        }
+        PMK_NCCL(g_rccl.AllGather(out, in, (size_t)(2 * maxc), ncclFloat64, c->comm, s));
+        for (int r = 0; r < W; ++r) {
+            if (r == c->rank && !c->force_exchange) continue;
+            if (scount[(size_t)r] > 0) {
+                PMK_HIP(hipMemcpyAsync(q->d_u + sfirst[(size_t)r], in + (int64_t)r * 2 * maxc, sizeof(double) * (size_t)scount[(size_t)r], hipMemcpyDeviceToDevice, s));
+                PMK_HIP(hipMemcpyAsync(q->d_v + sfirst[(size_t)r], in + (int64_t)r * 2 * maxc + maxc, sizeof(double) * (size_t)scount[(size_t)r], hipMemcpyDeviceToDevice, s));
+            }
+        }
+        c->bytes_sent = (int64_t)(W - 1) * 2 * maxc * 8;
+        c->bytes_recv = (int64_t)(W - 1) * 2 * maxc * 8;
+    }
+    return pmk_query_mix(q, weight_th, 0, q->Nq);
+}
+
+// payload bytes this rank sent / received in the exchange of its last predict step (either form)
+int pmk_comm_last_bytes(const pmk_comm *c, int64_t *sent, int64_t *received)
+{
+    if (!c) { set_error("pmk_comm_last_bytes: comm is NULL"); return -1; }
+    if (sent) *sent = c->bytes_sent;
+    if (received) *received = c->bytes_recv;
+    return 0;
 }
 
 }  // extern "C"

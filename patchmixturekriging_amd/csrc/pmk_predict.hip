@@ -204,9 +204,10 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
         if ((int)blockIdx.x >= nin) break;
         if (round > 0 && threadIdx.x == 0) {
             // round barrier of this XCD's workgroups (speed only, bounded): the strips of a round start together, so
-            // that the per-block-row rendezvous below only has to absorb small drifts.  Every earlier round was full.
+            // that the per-block-row rendezvous below only has to absorb small drifts.  Only the workgroups that have a task
+            // in this round arrive (the last round is usually partial: the others have left the loop above).
             uint32_t *cnt = sync_cnt + round_base + 8 * (round - 1) + (blockIdx.x & 7);
-            const uint32_t want = ((uint32_t)gridDim.x + 7u - (blockIdx.x & 7)) >> 3;   // workgroups with this id mod 8
+            const uint32_t want = ((uint32_t)nin + 7u - (blockIdx.x & 7)) >> 3;   // participants with this id mod 8
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (round_sync) {
                 const uint64_t t0 = __builtin_amdgcn_s_memrealtime();

@@ -103,8 +103,22 @@ def use_torch_stream(ctx):
     """run the library's kernels on torch's current stream: device work of the two then orders itself, and
     sharded_predict needs no host synchronisation between the library and torch.distributed"""
     import torch
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    handle = int(torch.cuda.current_stream().cuda_stream)
+    # torch's default stream is the device's legacy null stream, handle 0 -- which pmk_ctx_set_stream reads as "the
+    # context's own stream" (non-blocking: unordered with the null stream).  Name it explicitly.
+    if handle:
+        ctx.set_stream(handle)
+    else:
+        ctx.set_stream_null()
     ctx.shares_torch_stream = True
+    ctx.shared_stream_handle = handle
+
+
+def _shares_current_stream(ctx):
+    """the library really launches on the stream torch's work goes to right now"""
+    import torch
+    return bool(getattr(ctx, "shares_torch_stream", False)) and \
+        int(torch.cuda.current_stream().cuda_stream) == getattr(ctx, "shared_stream_handle", None)
 
 
 def sharded_predict(query, theta, weight_theta, radius, delta, P_global, rank, world, group=None):
@@ -120,7 +134,7 @@ def sharded_predict(query, theta, weight_theta, radius, delta, P_global, rank, w
         query.mix(weight_theta)
         return total
     model, ctx = query.model, query.model.ctx
-    shared = getattr(ctx, "shares_torch_stream", False)   # one stream for both: stream order replaces the host syncs
+    shared = _shares_current_stream(ctx)         # one stream for both: stream order replaces the host syncs
 
     def handoff():
         if not shared:
@@ -152,3 +166,60 @@ def sharded_predict(query, theta, weight_theta, radius, delta, P_global, rank, w
     handoff()
     query.mix(weight_theta)
     return total
+
+
+def allgather_slices(u_all, v_all, seg, rank, world, group=None):
+    """u_all / v_all: the region-sorted item buffers of a replicated plan, of which this rank has filled its own segment
+    seg[rank] = (first, count).  ONE all_gather of equal slices padded to the longest segment (sizes are known to every
+    rank from its own plan) fills in the other ranks' segments, in place.  Returns the payload bytes received."""
+    import torch
+    import torch.distributed as dist
+    maxc = max(1, max(n for _, n in seg))
+    f0, n0 = seg[rank]
+    out = torch.zeros(2 * maxc, dtype=torch.float64, device=u_all.device)
+    out[:n0] = u_all[f0:f0 + n0]
+    out[maxc:maxc + n0] = v_all[f0:f0 + n0]
+    if _comm_device(group) == "cpu" and out.is_cuda:     # gloo has no device path: staged through the host
+        parts = [torch.empty(2 * maxc, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, out.cpu(), group=group)
+        parts = [p.to(u_all.device) for p in parts]
+    else:
+        parts = [torch.empty(2 * maxc, dtype=torch.float64, device=out.device) for _ in range(world)]
+        dist.all_gather(parts, out, group=group)
+    for r, (f, n) in enumerate(seg):
+        if r != rank and n > 0:
+            u_all[f:f + n] = parts[r][:n]
+            v_all[f:f + n] = parts[r][maxc:maxc + n]
+    return (world - 1) * 2 * maxc * 8
+
+
+def allgather_predict(query, theta, weight_theta, radius, delta, P_global, rank, world, group=None):
+    """The north star's literal form of the predict step, driven over torch.distributed (the library's own version is
+    pmk_query_predict_allgather): `query` holds ALL queries of the job on every rank; every rank plans all of them,
+    evaluates the items that fall into its own leaves, ONE all-gather of equal padded (u, v) slices -- every rank knows
+    every slice's size from its own plan -- completes the item buffers, and every rank blends all queries.  Returns
+    (items of the job, payload bytes received by this rank)."""
+    import torch
+    import torch.distributed as dist
+    total = query.plan(radius, delta)
+    query.items(theta)
+    if world == 1:
+        query.mix(weight_theta)
+        return total, 0
+    model, ctx = query.model, query.model.ctx
+    shared = _shares_current_stream(ctx)
+
+    def handoff():
+        if not shared:
+            ctx.synchronize()
+            torch.cuda.synchronize()
+
+    seg = segments(query.region_offsets(P_global), world)
+    u_ptr, v_ptr = query.item_buffers()
+    u_all = torch.as_tensor(DevArray(u_ptr, max(total, 1)), device="cuda")
+    v_all = torch.as_tensor(DevArray(v_ptr, max(total, 1)), device="cuda")
+    handoff()
+    nbytes = allgather_slices(u_all, v_all, seg, rank, world, group)
+    handoff()
+    query.mix(weight_theta)
+    return total, nbytes

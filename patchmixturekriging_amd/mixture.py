@@ -196,6 +196,17 @@ class DeviceQuery:
         self.total = t.value
         return t.value
 
+    def predict_allgather(self, comm, theta, weight_theta, radius, delta):
+        """pmk_query_predict_allgather: the same step with REPLICATED queries (this object holds all of them): every
+        rank plans all queries, evaluates the items of its own leaves, one RCCL all-gather of padded (u, v) slices, every
+        rank blends all queries (collective).  Returns the item count of the whole job."""
+        d, w = theta.desc(), weight_theta.desc()
+        t = C.c_int64()
+        _lib.check(self.L.pmk_query_predict_allgather(self.h, comm.h, C.byref(d), C.byref(w), float(radius), float(delta),
+                                                      C.byref(t)), "pmk_query_predict_allgather")
+        self.total = t.value
+        return t.value
+
     def mix(self, weight_theta, q0=0, q1=None):
         d = weight_theta.desc()
         _lib.check(self.L.pmk_query_mix(self.h, C.byref(d), int(q0), int(self.Nq if q1 is None else q1)), "pmk_query_mix")

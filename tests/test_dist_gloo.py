@@ -126,6 +126,81 @@ def test_sharded_predict_matches_single_process_oracle(world, tmp_path):
     assert np.allclose(got_Y, oY, rtol=0, atol=1e-12) and np.allclose(got_V, oV, rtol=1e-10, atol=1e-15)
 
 
+def _worker_allgather(rank, world, port, tmp):
+    """the north star's literal form: replicated queries and plan, own-leaf items, one all-gather of padded (u, v) slices"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import patchmixturekriging_amd as pmk
+        from oracle import oracle as O
+        rng = np.random.Generator(np.random.PCG64(5))
+        N, levels, eps, a, sigma2, radius, delta = 600, 4, 0.5, 1 / 3.0, 1e-4, 0.6, 1e-5
+        X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+        y = np.sin(X[:, 0]) + 0.1 * X[:, 1]
+        Xq = np.stack([rng.uniform(-5, 5, 301), rng.uniform(-10, 10, 301)], 1)
+        root, _, _ = pmk.setuppartition(X, levels)
+        X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, X, eps)
+        P = len(X_set)
+        oth, owth = O.kernel(O.SPLINE34, a), O.kernel(O.SPLINE34, 1 / radius)
+        lo, hi = pd.leaf_range(rank, world, P)
+        fits = {r: O.fit_patch(oth, X_set[r], y[X_set_inds[r]], sigma2) for r in range(lo, hi)}
+        hps = pmk.fetchhyperplanes(root)
+        item_q, item_r, item_t, qoff = [], [], [], [0]
+        for j, x in enumerate(Xq):                                     # ALL queries on every rank
+            home = pmk.findpartition(x, root)
+            reg, ts, _, keep = pmk.findneighbourpartitions(x, radius, root, levels, hps, home, delta=delta)
+            item_q += [j] * (len(reg) + 1); item_r += list(reg) + [home]; item_t += list(ts[keep]) + [0.0]
+            qoff.append(len(item_q))
+        item_r = np.array(item_r); item_q = np.array(item_q); item_t = np.array(item_t)
+        order = np.argsort(item_r, kind="stable")
+        roff = np.concatenate([[0], np.cumsum(np.bincount(item_r, minlength=P))])
+        pos = np.empty(len(order), dtype=np.int64); pos[order] = np.arange(len(order))
+        total = len(order)
+        seg = pd.segments(roff, world)
+        u = torch.full((total,), float("nan"), dtype=torch.float64)
+        v = torch.full((total,), float("nan"), dtype=torch.float64)
+        f0, n0 = seg[rank]
+        for p_ in range(f0, f0 + n0):                                  # the items of this rank's leaves
+            it = order[p_]; r_ = int(item_r[it]); f = fits[r_]
+            u[p_], v[p_] = O.queryinner(oth, X_set[r_], f["c_lu"], f["L"], Xq[item_q[it]])
+        nbytes = pd.allgather_slices(u, v, seg, rank, world)
+        assert not torch.isnan(u).any() and not torch.isnan(v).any()
+        assert nbytes == (world - 1) * 2 * max(n for _, n in seg) * 8
+        Yq, Vq = np.empty(len(Xq)), np.empty(len(Xq))
+        for j in range(len(Xq)):                                       # every rank blends every query
+            its = np.arange(qoff[j], qoff[j + 1])
+            w = np.array([O.profile(owth, abs(t)) for t in item_t[its[:-1]]] + [1.0])
+            w = w / w.sum()
+            Yq[j] = w @ u[pos[its]].numpy()
+            Vq[j] = w @ (v[pos[its]].numpy() * w)
+        np.savez(os.path.join(tmp, "ag%d.npz" % rank), Yq=Yq, Vq=Vq)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_allgather_predict_matches_single_process_oracle(world, tmp_path):
+    mp.spawn(_worker_allgather, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import patchmixturekriging_amd as pmk
+    from oracle import oracle as O
+    rng = np.random.Generator(np.random.PCG64(5))
+    N, levels, eps, a, sigma2, radius, delta = 600, 4, 0.5, 1 / 3.0, 1e-4, 0.6, 1e-5
+    X = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+    y = np.sin(X[:, 0]) + 0.1 * X[:, 1]
+    Xq = np.stack([rng.uniform(-5, 5, 301), rng.uniform(-10, 10, 301)], 1)
+    root, _, _ = pmk.setuppartition(X, levels)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, X, eps)
+    oth, owth = O.kernel(O.SPLINE34, a), O.kernel(O.SPLINE34, 1 / radius)
+    ob = O.BSP(X, levels)
+    fits = [O.fit_patch(oth, xs, y[i], sigma2) for xs, i in zip(X_set, X_set_inds)]
+    oY, oV = O.query_mixture(ob, oth, owth, X_set, [f["c_lu"] for f in fits], [f["L"] for f in fits], Xq, radius, delta)
+    for r in range(world):                                             # every rank holds the whole result
+        d = np.load(os.path.join(str(tmp_path), "ag%d.npz" % r))
+        assert np.allclose(d["Yq"], oY, rtol=0, atol=1e-12) and np.allclose(d["Vq"], oV, rtol=1e-10, atol=1e-15)
+
+
 # ------------------------------------------------------------------------------------ config D shape: world 8, levels 11
 def _worker_counts(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -380,6 +380,9 @@ def test_config_C_full_size_properties():
         L, c = model.get(r, M.GET_L), model.get(r, M.GET_C)
         assert np.linalg.norm(L @ L.T - U) / np.linalg.norm(U) <= 1e-14
         assert np.linalg.norm(U @ c - yr) / (np.linalg.norm(U) * np.linalg.norm(c) + np.linalg.norm(yr)) <= 1e-13
+        f = O.fit_patch(oth, Xr, yr, 1e-5)                        # the factor itself, element by element, at n = 2000
+        assert f["info"] == 0 and np.abs(L - f["L"]).max() <= 1e-8
+        assert np.linalg.norm(c - f["c_chol"]) / np.linalg.norm(f["c_chol"]) <= 1e-6
     # linearity of the fit in y: c(y1 + 2 y2) = c(y1) + 2 c(y2)
     c1 = [model.get(r, M.GET_C) for r in (3, 200)]
     y2 = [np.cos(x[:, 0]) for x in X_parts]
@@ -427,6 +430,23 @@ def test_config_C_full_size_properties():
         worst_y = max(worst_y, abs(Yq[j] - yj) / max(1, abs(yj)))
         worst_v = max(worst_v, abs(Vq[j] - vj) / (1e-9 + 1e-5 * vj))
     assert worst_y <= 1e-7 and worst_v <= 1.0, (worst_y, worst_v)
+    # values at scale: every query whose home AND neighbours fall into 8 contiguous leaves, against the oracle's own
+    # querymixtureGP! with the oracle's own fits (LU weights, Cholesky factor) of those leaves -- >= 2000 queries
+    from concurrent.futures import ThreadPoolExecutor
+    P, leaves = 256, list(range(96, 104))
+    with ThreadPoolExecutor(8) as ex:
+        fits = list(ex.map(lambda r: O.fit_patch(oth, X_parts[r], y[X_parts_inds[r]], 1e-5), leaves))
+    inside = np.zeros(P, bool); inside[leaves] = True
+    ok = np.add.reduceat(~inside[dbg["item_region"]], dbg["item_offsets"][:-1]) == 0
+    qs = np.nonzero(ok)[0]
+    assert len(qs) >= 2000, len(qs)
+    qs = qs[:6000]
+    Xs = [X_parts[r] if inside[r] else X_parts[r][:1] for r in range(P)]
+    cs = [fits[r - leaves[0]]["c_lu"] if inside[r] else np.zeros(1) for r in range(P)]
+    Ls = [fits[r - leaves[0]]["L"] if inside[r] else np.ones((1, 1)) for r in range(P)]
+    oY, oV = O.query_mixture(ob, oth, O.kernel(O.SPLINE34, 1 / 0.088), Xs, cs, Ls, Xq[qs], 0.088, 1e-5, nthreads=8)
+    assert np.all(np.abs(Yq[qs] - oY) <= 1e-7 * np.maximum(1, np.abs(oY)))
+    assert np.all(np.abs(Vq[qs] - oV) <= 1e-9 + 1e-5 * oV)
 
 
 def test_pipelined_kernel_matrix_build_is_bit_identical():
@@ -684,6 +704,14 @@ def test_rccl_exchange_inside_the_library_loopback():
         assert q3.predict_sharded(comm, th, wth, radius, delta) == total
         Y2, V2 = q3.fetch()
         assert np.array_equal(Y2[::-1], Y0) and np.array_equal(V2[::-1], V0)
+    # the all-gather form (replicated queries): one rank, the gather forced through RCCL
+    for _ in range(2):
+        q4 = pmk.DeviceQuery(m, Xq)
+        assert q4.predict_allgather(comm, th, wth, radius, delta) == total
+        Y3, V3 = q4.fetch()
+        assert np.array_equal(Y3, Y0) and np.array_equal(V3, V0)
+    sent, recv = comm.last_bytes()
+    assert sent == 0 and recv == 0                                   # world 1: nothing leaves the rank
     # a model that does not hold rank's share of the leaves is refused
     half = pmk.DeviceModel(X_set[:4], ys[:4]); half.fit(th, 1e-5); half.set_bsp(root, 0)
     with pytest.raises(pmk.PmkError):
@@ -691,19 +719,33 @@ def test_rccl_exchange_inside_the_library_loopback():
     comm.close()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 @pytest.mark.timeout(600)
-def test_two_ranks_share_one_gpu(tmp_path):
+@pytest.mark.parametrize("stream,nq,exchange", [("default", 3001, "requests"), ("side", 3001, "requests"),
+                                                ("default", 200001, "requests"), ("default", 3001, "allgather"),
+                                                ("side", 20001, "allgather")])
+def test_two_ranks_share_one_gpu(tmp_path, stream, nq, exchange):
     """Two fresh child ranks (gloo; both on cuda:0) run patchmixturekriging_amd.dist.sharded_predict -- per-rank
     leaf_base models, region-sorted segments, counts, the two all-to-alls into library-owned device buffers, all on one
-    stream -- and their slices must equal the single-model result of this process bit for bit."""
+    stream with NO host synchronisation in between -- and their slices must equal the single-model result of this
+    process bit for bit.  On torch's default stream (handle 0 = the legacy null stream, which the library must be told
+    to use explicitly), under a side stream, and on the default stream with an items kernel long enough (200 001
+    queries) that an unordered copy would read its outputs early."""
     import subprocess
     import sys
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PMK_TEST_STREAM=stream,
+               PMK_TEST_NQ=str(nq), PMK_TEST_EXCHANGE=exchange)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), str(tmp_path)]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), str(tmp_path)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    X, y, Xq = _mixgp_case(6000, 4, 0.4, 1 / 4.0, 1e-5, 0.6, 1e-5, 3001, 11)
+    X, y, Xq = _mixgp_case(6000, 4, 0.4, 1 / 4.0, 1e-5, 0.6, 1e-5, nq, 11)
     y = np.sin(X[:, 0]) * np.cos(0.3 * X[:, 1])
     th, wth = pmk.Spline34KernelType(1 / 4.0), pmk.Spline34KernelType(1 / 0.6)
     root, _, _ = pmk.setuppartition(X, 4)
