@@ -59,6 +59,34 @@ def executed_step_flops(n, tile=128):
     return f
 
 
+def kernel_source_hash():
+    """identity of the device code this run executes: sha256 over the kernel sources of libpmk_hip.so (what a PMC summary
+    must have been taken on for its byte counts to mean anything for this run)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "patchmixturekriging_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
+
+
+def load_pmc_summary():
+    """(summary, source) -- the summary only if it was collected on this build of the kernels, else (None, why)"""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))
+    except Exception:
+        return None, "no %s" % PMC_SUMMARY
+    have, want = pmc.get("kernel_source_hash"), kernel_source_hash()
+    if have != want:
+        return None, "%s is stale (kernel sources %s, summary taken on %s): traffic dropped" % (PMC_SUMMARY, want, have)
+    return pmc, PMC_SUMMARY
+
+
 def host_cores():
     """threads the CPU leg may use: the affinity mask, capped by the cgroup CPU quota of the box (a GPU box may show every
     core of the host in its mask while the container is entitled to a share of them)"""
@@ -93,10 +121,58 @@ def main():
                     help="overlap of the training sets (organizetrainingsets); 0.044 gives the ragged 'realistic' "
                          "variant of config C (n ~ 1.8k-2.2k per patch, SURVEY 8(d))")
     ap.add_argument("--config", default="C", choices=["C", "D", "E"])
-    ap.add_argument("--exchange", default=os.environ.get("PMK_BENCH_EXCHANGE", "abi"), choices=["abi", "torch"],
-                    help="N > 1: 'abi' = pmk_query_predict_sharded (the library's own RCCL communicator); 'torch' = the "
-                         "same step driven from Python over torch.distributed (patchmixturekriging_amd/dist.py)")
+    ap.add_argument("--exchange", default=os.environ.get("PMK_BENCH_EXCHANGE", "abi"),
+                    choices=["abi", "torch", "allgather", "allgather-torch"],
+                    help="N > 1: 'abi' = pmk_query_predict_sharded (requests to the leaf owners and (u, v) back, the library's "
+                         "own RCCL communicator); 'torch' = the same step driven from Python over torch.distributed "
+                         "(patchmixturekriging_amd/dist.py); 'allgather' = BASELINE.json's literal form, "
+                         "pmk_query_predict_allgather: REPLICATED queries, every rank plans all of them, one ncclAllGather of "
+                         "padded (u, v) slices; 'allgather-torch' = that form over torch.distributed")
+    ap.add_argument("--shard-queries", default="index", choices=["index", "home"],
+                    help="which queries a rank holds (request/response exchanges): 'index' = an equal slice of the query "
+                         "array; 'home' = the queries whose home leaf it owns (routed once, before the timed region: only "
+                         "items that cross a subtree boundary then travel)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block (reference-named API wall times)")
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        # launched plainly (python bench.py --gpus N): start N fresh ranks and relay rank 0's line.  This process has not
+        # imported torch or touched a GPU, and it never replaces itself: the ranks are children.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus))
+        procs = []
+        for r_ in range(args.gpus):            # what torch.distributed.run would set, one child per rank
+            e = dict(env, RANK=str(r_), LOCAL_RANK=str(r_))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                          stdout=subprocess.PIPE if r_ == 0 else subprocess.DEVNULL, text=True))
+        import threading
+        buf = []
+        rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()))
+        rd.start()
+        while any(p_.poll() is None for p_ in procs):
+            if any(p_.poll() not in (None, 0) for p_ in procs):     # a rank died: its peers would wait in a collective for ever
+                for p_ in procs:
+                    if p_.poll() is None:
+                        p_.kill()
+                break
+            time.sleep(0.2)
+        rcs = [p_.wait() for p_ in procs]
+        rd.join()
+        out0 = buf[0] if buf else ""
+        lines = [ln for ln in out0.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        for ln in out0.splitlines():
+            if ln not in lines:
+                print(ln, file=sys.stderr)
+        if lines:
+            print(lines[-1])
+        rc = next((c for c in rcs if c), 0)
+        sys.exit(rc if rc else (0 if lines else 1))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -119,7 +195,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-            args.exchange = "torch"             # two ranks on one device: RCCL refuses duplicate GPUs
+            # two ranks on one device: RCCL refuses duplicate GPUs, so the library's communicator is out
+            args.exchange = {"abi": "torch", "allgather": "allgather-torch"}.get(args.exchange, args.exchange)
 
     import patchmixturekriging_amd as pmk
     from patchmixturekriging_amd import dist as pdist
@@ -164,12 +241,23 @@ def main():
     model.set_bsp(root, lo)
     Nq = nq * world
     Xq = rng.uniform(0, 1, (Nq, 3)) if cfgE else np.stack([rng.uniform(-5, 5, Nq), rng.uniform(-10, 10, Nq)], 1)
-    query = pmk.DeviceQuery(model, Xq[rank * nq:(rank + 1) * nq])   # queries are sharded like the leaves
+    replicated = world > 1 and args.exchange.startswith("allgather")
+    if replicated:
+        Xq_mine = Xq                                 # the all-gather form: every rank holds (and plans) every query
+    elif world > 1 and args.shard_queries == "home":
+        # route once, outside the timed region: a rank holds the queries whose home leaf it owns
+        tmp = pmk.DeviceQuery(model, Xq); tmp.plan(radius, delta)
+        home = tmp.debug()["home"]
+        del tmp
+        Xq_mine = Xq[(home >= lo) & (home < hi)]
+    else:
+        Xq_mine = Xq[rank * nq:(rank + 1) * nq]      # queries are sharded like the leaves
+    query = pmk.DeviceQuery(model, Xq_mine)
 
     comm, exchange = None, "none"
     if world > 1:
         exchange = args.exchange
-        if exchange == "abi":
+        if exchange in ("abi", "allgather"):
             try:
                 idt = torch.zeros(pmk.context.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
                 if rank == 0:
@@ -179,12 +267,12 @@ def main():
             except Exception as e:                                  # say so loudly; the step itself is the same
                 print("bench.py: the library's RCCL communicator could not be created (%s); using torch.distributed" % e,
                       file=sys.stderr)
-                exchange = "torch"
-            flag = torch.tensor([1 if exchange == "torch" else 0], device="cuda")
+                exchange = {"abi": "torch", "allgather": "allgather-torch"}[exchange]
+            flag = torch.tensor([1 if exchange.endswith("torch") else 0], device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)              # all ranks must take the same path
-            if int(flag.item()) and exchange == "abi":
+            if int(flag.item()) and not exchange.endswith("torch"):
                 comm.close()
-                comm, exchange = None, "torch"
+                comm, exchange = None, {"abi": "torch", "allgather": "allgather-torch"}[exchange]
 
     def sync():
         torch.cuda.synchronize()
@@ -226,10 +314,14 @@ def main():
                 stage_ms[k].append(ctx.timer_ms(k))
             except pmk.PmkError:
                 pass
-        try:
-            step_us.append([ctx.timer_ms("step:%d" % i) * 1e3 for i in range(nt_max - 1)])
-        except pmk.PmkError:
-            pass
+        us = []
+        for i in range(nt_max):                  # however many launches the factorisation made (the queue form: one)
+            try:
+                us.append(ctx.timer_ms("step:%d" % i) * 1e3)
+            except pmk.PmkError:
+                break
+        if us:
+            step_us.append(us)
     stage = {k: float(np.median(v)) for k, v in stage_ms.items() if v}
     if "panel" in stage:
         stage["chol_steps"] = stage.pop("panel")        # the nt - 1 chol_step_kernel launches of a fit
@@ -238,6 +330,10 @@ def main():
     def predict_step():
         # plan of this rank's queries (K5 + sort) -> requests to the leaf owners -> items (K4) -> (u, v) back (RCCL over
         # xGMI) -> mixture (K6)
+        if exchange == "allgather":
+            return query.predict_allgather(comm, th, wth, radius, delta)
+        if exchange == "allgather-torch":
+            return pdist.allgather_predict(query, th, wth, radius, delta, P * world, rank, world)[0]
         if comm is not None:
             return query.predict_sharded(comm, th, wth, radius, delta)
         return pdist.sharded_predict(query, th, wth, radius, delta, P * world, rank, world)
@@ -245,6 +341,20 @@ def main():
     ctx.L.pmk_ctx_enable_timers(ctx.h, 0)
     total_items = predict_step()
     dt_pred = timed(predict_step, args.steps, max(1, args.warmup - 1))
+    xbytes = None
+    if world > 1:
+        if comm is not None:
+            sent, recv = comm.last_bytes()
+        elif exchange == "allgather-torch":
+            recv = pdist.allgather_predict(query, th, wth, radius, delta, P * world, rank, world)[1]; sent = recv
+        else:
+            sent = recv = None
+        if sent is not None:
+            tb = torch.tensor([sent, recv, total_items, len(Xq_mine)], device="cuda", dtype=torch.int64)
+            tl = [torch.zeros_like(tb) for _ in range(world)]
+            dist.all_gather(tl, tb)
+            xbytes = {"sent_per_rank": [int(t[0]) for t in tl], "received_per_rank": [int(t[1]) for t in tl],
+                      "items_per_rank": [int(t[2]) for t in tl], "queries_per_rank": [int(t[3]) for t in tl]}
     ctx.L.pmk_ctx_enable_timers(ctx.h, 1)
     predict_step()
     ctx.synchronize()
@@ -297,7 +407,7 @@ def main():
     alg = sum(chol_flops(s) for s in mine)
     roof = None
     if "chol_steps" in stage and nt_max > 1:
-        launches = nt_max - 1
+        launches = len(step_us[0]) if step_us else nt_max - 1
         t_steps = stage["chol_steps"] * 1e-3
         roof = {"bound": "mfma", "kernel": "chol_step_kernel",
                 "achieved": alg / t_steps / 1e12, "peak": peak, "unit": "TFLOP/s",
@@ -314,13 +424,14 @@ def main():
             roof["shader_clock_ghz"] = ghz
             roof["frac_of_peak_at_that_clock"] = roof["frac"] * NOMINAL_GHZ / ghz
             roof["executed_flops_frac_at_that_clock"] = roof["executed_flops_frac"] * NOMINAL_GHZ / ghz
-        try:    # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
-            if cfg == "C" and (P, n) == (256, 2000) and args.eps == 0:
-                roof["traffic"] = pmc["chol_step_kernel"]["hbm_bytes_per_dispatch"]
-                roof["traffic_source"] = "profiles/r02_pmc_summary.json"
-        except Exception:
-            pass
+        # HBM bytes per launch from the committed PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE) -- only if
+        # they were taken on THIS build of the kernels (the summary carries the hash of the kernel sources)
+        pmc, pmc_src = load_pmc_summary()
+        if pmc is not None and cfg == "C" and (P, n) == (256, 2000) and args.eps == 0 and "chol_step_kernel" in pmc:
+            roof["traffic"] = pmc["chol_step_kernel"].get("hbm_bytes_per_dispatch")
+            roof["traffic_source"] = pmc_src
+        elif pmc is None:
+            roof["traffic_source"] = pmc_src
     ms = dt_fit / args.steps * 1e3
     roof_fit = {"bound": "mfma", "achieved": alg / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": alg / (ms * 1e-3) / 1e12 / peak, "note": "algorithmic flops / ms_per_step (K1 + factor + solves)"}
@@ -344,12 +455,39 @@ def main():
         if ghz > 0:
             roof_pred["shader_clock_ghz"] = ghz
             roof_pred["frac_of_peak_at_that_clock"] = roof_pred["frac"] * NOMINAL_GHZ / ghz
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
-            if cfg == "C" and (P, n, nq) == (256, 2000, 1 << 20) and args.eps == 0:
-                roof_pred["traffic"] = pmc["predict_strip_kernel"]["hbm_bytes_per_dispatch"]
-        except Exception:
-            pass
+        pmc, pmc_src = load_pmc_summary()
+        if pmc is not None and cfg == "C" and (P, n, nq) == (256, 2000, 1 << 20) and args.eps == 0 and "predict_strip_kernel" in pmc:
+            roof_pred["traffic"] = pmc["predict_strip_kernel"].get("hbm_bytes_per_dispatch")
+            roof_pred["traffic_source"] = pmc_src
+
+    # ---------------------------------------------------------------- end to end: the reference's own timing points
+    # examples/mixGP.jl:154 `@time fitmixtureGP!` and :176 `@time querymixtureGP!`, through the reference-named API with host
+    # buffers on both sides (model creation, H2D of X / y / Xq, D2H of c, Yq, Vq included): wall clock, median of >= 10
+    e2e = None
+    if world == 1 and not args.no_e2e and not cfgE:
+        reps = 10
+        hps = pmk.fetchhyperplanes(root)
+        Y_set = [y[i] for i in X_parts_inds]
+        eta = pmk.MixtureGPType(X_parts, hps)
+        t_fit, t_q = [], []
+        for _ in range(reps + 1):
+            t = time.perf_counter()
+            pmk.fitmixtureGP_(eta, Y_set, th, sigma2)
+            t_fit.append(time.perf_counter() - t)
+        nq_e = min(Nq, 1 << 20)
+        Yo, Vo = np.empty(0), np.empty(0)
+        for _ in range(reps + 1):
+            t = time.perf_counter()
+            Yo, Vo = pmk.querymixtureGP_(Yo, Vo, Xq[:nq_e], eta, root, levels, radius, delta, th, sigma2, wth,
+                                         pmk.MixtureGPDebugType(1.0)) or (Yo, Vo)
+            t_q.append(time.perf_counter() - t)
+        e2e = {"fitmixtureGP_ms": float(np.median(t_fit[1:]) * 1e3), "querymixtureGP_ms": float(np.median(t_q[1:]) * 1e3),
+               "patch_solves_per_s": P / float(np.median(t_fit[1:])), "predict_points_per_s": nq_e / float(np.median(t_q[1:])),
+               "queries": nq_e, "repetitions": reps,
+               "what": "host wall clock of the reference-named calls (mixture.py mirrors of mixtureGP.jl:70-118, 159-294): "
+                       "device model created and X, y uploaded inside fitmixtureGP_, c downloaded; Xq uploaded and Yq, Vq "
+                       "downloaded inside querymixtureGP_; median of %d after one warm-up" % reps}
+        del eta
 
     # ---------------------------------------------------------------- CPU baseline (oracle = port), rank 0, N = 1
     cpu = None
@@ -444,16 +582,23 @@ def main():
                    "patches_per_gpu": P, "points_per_patch": n, "patch_sizes_minmax": [min(sizes), max(sizes)],
                    "eps": args.eps, "queries_per_gpu": nq, "radius": radius, "items_per_query": total_items / nq,
                    "levels": levels,
-                   "parallelism": "leaves and queries sharded (%d leaves per GPU); requests to the leaf owners and (u,v) back by "
-                                  "grouped RCCL send/recv" % P,
-                   "exchange": exchange, "bsp_build_s": t_bsp},
+                   "parallelism": ("leaves sharded (%d per GPU), queries REPLICATED; one RCCL all-gather of padded (u,v) slices" % P)
+                                  if replicated else
+                                  ("leaves and queries sharded (%d leaves per GPU, queries by %s); requests to the leaf owners and "
+                                   "(u,v) back by grouped RCCL send/recv" % (P, args.shard_queries)),
+                   "exchange": exchange, "shard_queries": "replicated" if replicated else args.shard_queries,
+                   "bsp_build_s": t_bsp},
         "stage_ms": {**stage, **{"predict_" + k: v for k, v in pstage.items()}},
         "roofline": roof,
         "roofline_fit_step": roof_fit,
         "roofline_kernel_matrix": roof_k1,
         "roofline_predict": roof_pred,
         "cpu_baseline": cpu,
+        "end_to_end": e2e,
+        "kernel_source_hash": kernel_source_hash(),
     }
+    if xbytes is not None:
+        out["exchange_bytes"] = xbytes
     if parity32 is not None:
         out["parity_vs_fp64"] = parity32
     print(json.dumps(out))

@@ -317,6 +317,10 @@ def querymixtureGP_(Yq, Vq, Xq, eta, root, levels, radius, delta, theta, sigma2,
         dbg = q.debug()
         off = dbg["item_offsets"]
         hps = eta.hps
+        # the reference resize!s every field to Nq and assigns (mixtureGP.jl:185-195): a reused debug struct does not grow
+        for name in ("w_tilde_set", "u_set", "v_set", "region_inds_set", "p_region_ind_set", "hps_keep_flags_set", "zs_set",
+                     "ts_set"):
+            getattr(debug_vars, name).clear()
         for j in range(q.Nq):
             s = slice(off[j], off[j + 1])
             debug_vars.w_tilde_set.append(dbg["item_w"][s].copy())

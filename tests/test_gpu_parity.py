@@ -1221,3 +1221,26 @@ def test_task_queue_factorisation_is_bit_identical_to_the_step_launches(monkeypa
             continue
         for (c0, L0, N0), (c1, L1, N1) in zip(ref, got):
             assert np.array_equal(c0, c1) and np.array_equal(L0, L1) and np.array_equal(N0, N1)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("extra", [[], ["--exchange", "allgather"], ["--shard-queries", "home"]])
+def test_bench_launched_plainly_with_two_ranks(extra):
+    """`python bench.py --gpus 2` with no launcher around it: the parent (which has not touched the GPU) starts two fresh
+    ranks itself and relays rank 0's line.  Rehearsed on this one-GPU box with both ranks on cuda:0 over gloo; the
+    request/response exchange, the all-gather form and home-leaf query sharding."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PMK_BENCH_SHARE_GPU="1", PMK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--patches", "16",
+           "--n", "600", "--nq", "20000", "--no-cpu"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["predict_points_per_s"] > 0
+    assert d["config"]["exchange"] in ("torch", "allgather-torch")
+    if extra[:1] == ["--exchange"]:
+        assert d["config"]["shard_queries"] == "replicated" and d["exchange_bytes"]["received_per_rank"][0] > 0

@@ -19,7 +19,7 @@ python3 - "$out/summary.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 for k, v in d.items():
-    if "hbm_bytes_per_dispatch" in v:
+    if isinstance(v, dict) and "hbm_bytes_per_dispatch" in v:
         print("%-24s HBM %.3f GB/dispatch (fetch x2 %.3f + write %.3f), L2 hit %.3f, mfma_busy %.3f, dispatches %d" % (
             k, v["hbm_bytes_per_dispatch"] / 1e9, 2 * v["FETCH_SIZE"]["mean_per_dispatch"] * 1024 / 1e9,
             v["WRITE_SIZE"]["mean_per_dispatch"] * 1024 / 1e9, v.get("l2_hit_rate", -1), v.get("mfma_busy_frac", -1),

@@ -45,6 +45,10 @@ def main():
             # MFMA-busy cycles summed over SIMDs / (GPU-active cycles x 1024 SIMDs); GRBM_GUI_ACTIVE sums the 8 XCDs
             d["mfma_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_dispatch"] / max(
                 d["GRBM_GUI_ACTIVE"]["mean_per_dispatch"] / 8.0 * 1024.0, 1.0)
+    # the build the counters were taken on: bench.py only quotes these byte counts for the same kernel sources
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
+    out["kernel_source_hash"] = kernel_source_hash()
     print(json.dumps(out, indent=1))
 
 

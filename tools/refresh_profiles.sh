@@ -3,7 +3,7 @@
 #     tools/refresh_profiles.sh r02
 # writes gpurun_out/<tag>/...; copy what is to be judged into profiles/ afterwards (tools/collect_profiles.py).
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
