@@ -335,19 +335,44 @@ mutable struct MixtureGPDebugType{T}      # mixtureGP.jl:5-35
 end
 MixtureGPDebugType(dummy_val::T) where T = MixtureGPDebugType{T}([], [], [], [], [], [], [], [])
 
+"""U_set / L_set of a fitted model (mixtureGP.jl:43-46): the factors stay on the device (2 x 8 nÂ² bytes per patch, 16.8 GB
+at 256 x 2000) and `Î·.L_set[r]` / `Î·.U_set[r]` pull ONE patch to the host on first use and keep it, as the Python mirror
+does (mixture.py, _LazyFactors).  Indexes and iterates like the reference's Vector."""
+mutable struct LazyFactors{T,M} <: AbstractVector{M}
+    model::Ref{Ptr{Cvoid}}      # shared with the MixtureGPType that owns the device model
+    what::Int                   # pmk_model_get selector: 1 = L (chol_U.L), 2 = K without noise (U_set)
+    n::Vector{Int}
+    cache::Dict{Int,M}
+end
+Base.size(f::LazyFactors) = (length(f.n),)
+Base.IndexStyle(::Type{<:LazyFactors}) = IndexLinear()
+function Base.getindex(f::LazyFactors{T,M}, r::Int) where {T,M}
+    haskey(f.cache, r) && return f.cache[r]
+    f.model[] == C_NULL && throw(PMKError("fitmixtureGP! must run before U_set / L_set are read"))
+    A = Matrix{T}(model_get(f.model[], r, f.what, f.n[r]))
+    f.cache[r] = f.what == 1 ? LowerTriangular(A) : A          # exactly M in either case
+    return f.cache[r]
+end
+Base.setindex!(f::LazyFactors, v, r::Int) = (f.cache[r] = v)
+
 mutable struct MixtureGPType{T}           # mixtureGP.jl:38-52 (+ the device model handle)
     X_parts::Vector{Vector{Vector{T}}}
     c_set::Vector{Vector{T}}
     ÏƒÂ²_set::Vector{T}
-    U_set::Vector{Matrix{T}}
-    L_set::Vector{LowerTriangular{T,Matrix{T}}}
+    U_set::LazyFactors{T,Matrix{T}}
+    L_set::LazyFactors{T,LowerTriangular{T,Matrix{T}}}
     hps::Vector{HyperplaneType{T}}
     model::Ptr{Cvoid}
+    handle::Ref{Ptr{Cvoid}}     # the same handle, shared with U_set / L_set
 end
 function MixtureGPType(X_parts::Vector{Vector{Vector{T}}}, hps::Vector{HyperplaneType{T}}) where T
     N = length(X_parts)
-    Î· = MixtureGPType(X_parts, Vector{Vector{T}}(undef, N), Vector{T}(undef, N), Vector{Matrix{T}}(undef, N),
-                      Vector{LowerTriangular{T,Matrix{T}}}(undef, N), hps, C_NULL)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    n = Int[length(X) for X in X_parts]
+    Î· = MixtureGPType{T}(X_parts, Vector{Vector{T}}(undef, N), Vector{T}(undef, N),
+                         LazyFactors{T,Matrix{T}}(h, 2, n, Dict{Int,Matrix{T}}()),
+                         LazyFactors{T,LowerTriangular{T,Matrix{T}}}(h, 1, n, Dict{Int,LowerTriangular{T,Matrix{T}}}()),
+                         hps, C_NULL, h)
     finalizer(e -> (e.model != C_NULL && ccall((:pmk_model_destroy, libpmk), Cvoid, (Ptr{Cvoid},), e.model); nothing), Î·)
     return Î·
 end
@@ -359,16 +384,19 @@ function model_get(model::Ptr{Cvoid}, r::Int, what::Int, n::Int)
     return out
 end
 
-"""fitmixtureGP!(Î·, y_parts, Î¸, ÏƒÂ²) -> Î· (mixtureGP.jl:70-118).  Pass store_factors=false to keep L_set/U_set
-on the device only (they are 2 x 8 nÂ² bytes per patch on the host)."""
-function fitmixtureGP!(Î·::MixtureGPType{T}, y_parts::Vector{Vector{T}}, Î¸, ÏƒÂ²; store_factors::Bool = true) where T
+"""fitmixtureGP!(Î·, y_parts, Î¸, ÏƒÂ²) -> Î· (mixtureGP.jl:70-118).  c_set comes back to the host; U_set / L_set are read from
+the device patch by patch when they are first indexed (LazyFactors); store_factors = true pulls all of them at once."""
+function fitmixtureGP!(Î·::MixtureGPType{T}, y_parts::Vector{Vector{T}}, Î¸, ÏƒÂ²; store_factors::Bool = false) where T
     P = length(Î·.X_parts)
     Xm = [pack(X) for X in Î·.X_parts]; ys = [Vector{Float64}(y) for y in y_parts]
     n = Int64[size(x, 2) for x in Xm]; D = size(Xm[1], 1)
     for r = 1:P
         @assert length(ys[r]) == n[r]                      # mixtureGP.jl:298
     end
-    Î·.model != C_NULL && ccall((:pmk_model_destroy, libpmk), Cvoid, (Ptr{Cvoid},), Î·.model)
+    if Î·.model != C_NULL
+        ccall((:pmk_model_destroy, libpmk), Cvoid, (Ptr{Cvoid},), Î·.model)
+        Î·.model = C_NULL; Î·.handle[] = C_NULL
+    end
     h = Ref{Ptr{Cvoid}}(C_NULL); info = Vector{Int32}(undef, P); d = Ref(desc(Î¸))
     GC.@preserve Xm ys begin
         rc = ccall((:pmk_fit_batched, libpmk), Cint,
@@ -378,14 +406,16 @@ function fitmixtureGP!(Î·::MixtureGPType{T}, y_parts::Vector{Vector{T}}, Î¸, ÏƒÂ
     end
     check(rc, "fitmixtureGP!")
     Î·.model = h[]
+    Î·.handle[] = h[]
+    empty!(Î·.U_set.cache); empty!(Î·.L_set.cache)
+    Î·.U_set.n = Int.(n); Î·.L_set.n = Int.(n)
     bad = findfirst(!=(0), info)
     bad === nothing || throw(PosDefException(Int(info[bad])))       # cholesky(U) of mixtureGP.jl:109
     for r = 1:P
         Î·.c_set[r] = model_get(Î·.model, r, 0, Int(n[r]))
         Î·.ÏƒÂ²_set[r] = ÏƒÂ²
         if store_factors
-            Î·.L_set[r] = LowerTriangular(model_get(Î·.model, r, 1, Int(n[r])))
-            Î·.U_set[r] = model_get(Î·.model, r, 2, Int(n[r]))
+            Î·.L_set[r]; Î·.U_set[r]                                  # pulled and cached
         end
     end
     return Î·
@@ -415,13 +445,17 @@ function querymixtureGP!(Yq::Vector{T}, Vq::Vector{T}, Xq::Vector{Vector{T}}, Î·
             check(ccall((:pmk_query_debug, libpmk), Cint,
                 (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
                 q[], home, off, reg, t, w, u, v), "pmk_query_debug")
+            # the reference resize!s every field to Nq and assigns (mixtureGP.jl:185-195): a reused struct does not grow
+            resize!(debug_vars.w_tilde_set, Nq); resize!(debug_vars.u_set, Nq); resize!(debug_vars.v_set, Nq)
+            resize!(debug_vars.region_inds_set, Nq); resize!(debug_vars.p_region_ind_set, Nq)
+            resize!(debug_vars.hps_keep_flags_set, Nq); resize!(debug_vars.zs_set, Nq); resize!(debug_vars.ts_set, Nq)
             for j = 1:Nq
                 s = off[j]+1:off[j+1]
-                push!(debug_vars.w_tilde_set, w[s]); push!(debug_vars.u_set, u[s]); push!(debug_vars.v_set, v[s])
-                push!(debug_vars.region_inds_set, Vector{Int}(reg[s[1:end-1]] .+ 1))
-                push!(debug_vars.p_region_ind_set, Int(home[j]) + 1)
+                debug_vars.w_tilde_set[j] = w[s]; debug_vars.u_set[j] = u[s]; debug_vars.v_set[j] = v[s]
+                debug_vars.region_inds_set[j] = Vector{Int}(reg[s[1:end-1]] .+ 1)
+                debug_vars.p_region_ind_set[j] = Int(home[j]) + 1
                 _, ts, zs, keep = findneighbourpartitions(Xq[j], radius, root, levels, Î·.hps, Int(home[j]) + 1; Î´ = Î´)
-                push!(debug_vars.hps_keep_flags_set, keep); push!(debug_vars.zs_set, zs); push!(debug_vars.ts_set, ts)
+                debug_vars.hps_keep_flags_set[j] = keep; debug_vars.zs_set[j] = zs; debug_vars.ts_set[j] = ts
             end
         end
     finally
@@ -511,21 +545,35 @@ querymixtureGP(xq::Vector{T}, Î·::MixtureGPType{T}, root, levels, radius::T, Î´:
 
 """queryinner(xq, X, Î¸, c, L) -> (Î¼, ÏƒÂ²) (mixtureGP.jl:296-320): host factors are uploaded with pmk_model_load and
 one strip of the prediction kernel runs against them"""
+# the last (X, c, L) that queryinner uploaded, by identity: a loop over query points against one patch (dev/debug.jl:46)
+# moves the n x n factor to the device once, not once per point
+mutable struct InnerCache
+    key::Tuple{UInt,UInt,UInt}
+    model::Ptr{Cvoid}
+end
+const INNER_CACHE = InnerCache((UInt(0), UInt(0), UInt(0)), C_NULL)
+
 function queryinner(xq::Vector{T}, X, Î¸, c, L) where T
-    Xm = pack(X); D, n = size(Xm)
-    cc = Vector{Float64}(c); Lm = Matrix{Float64}(L)
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve Xm cc Lm begin
-        check(ccall((:pmk_model_load, libpmk), Cint,
-            (Ptr{Cvoid}, Cint, Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
-            context(), D, 1, Int64[n], [pointer(Xm)], [pointer(cc)], [pointer(Lm)], Int64[n], h), "pmk_model_load")
+    key = (objectid(X), objectid(c), objectid(L))
+    if INNER_CACHE.model == C_NULL || INNER_CACHE.key != key
+        if INNER_CACHE.model != C_NULL
+            ccall((:pmk_model_destroy, libpmk), Cvoid, (Ptr{Cvoid},), INNER_CACHE.model)
+            INNER_CACHE.model = C_NULL
+        end
+        Xm = pack(X); D, n = size(Xm)
+        cc = Vector{Float64}(c); Lm = Matrix{Float64}(L)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve Xm cc Lm begin
+            check(ccall((:pmk_model_load, libpmk), Cint,
+                (Ptr{Cvoid}, Cint, Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
+                context(), D, 1, Int64[n], [pointer(Xm)], [pointer(cc)], [pointer(Lm)], Int64[n], h), "pmk_model_load")
+        end
+        INNER_CACHE.model = h[]; INNER_CACHE.key = key
     end
     Î¼ = Ref{Float64}(0.0); v = Ref{Float64}(0.0)
-    rc = ccall((:pmk_model_queryinner, libpmk), Cint,
+    check(ccall((:pmk_model_queryinner, libpmk), Cint,
         (Ptr{Cvoid}, Int64, Ref{KernelDesc}, Int64, Ptr{Float64}, Ref{Float64}, Ref{Float64}),
-        h[], 0, Ref(desc(Î¸)), 1, Vector{Float64}(xq), Î¼, v)
-    ccall((:pmk_model_destroy, libpmk), Cvoid, (Ptr{Cvoid},), h[])
-    check(rc, "queryinner")
+        INNER_CACHE.model, 0, Ref(desc(Î¸)), 1, Vector{Float64}(xq), Î¼, v), "queryinner")
     return Î¼[], v[]
 end
 queryinner!(kq::Vector{T}, xq, X, Î¸, c, L; min_v = 1e-12) where T = queryinner(xq, X, Î¸, c, L)

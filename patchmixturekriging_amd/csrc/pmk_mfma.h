@@ -305,6 +305,78 @@ __device__ __forceinline__ void gemm_nt_indexed(WaveTile<NPI, NPJ> &t, const rea
     for (int k0 = PEEL ? 4 * PFJ : 0; k0 < K; k0 += 4 * PFJ) pass(k0);
 }
 
+// Buffer-load form of the same product (tools/gemm_probe.hip: 96.2 % of the fp64 MFMA peak with two waves per SIMD,
+// 94.0 % alone, against 94.0 / 91.7 % for the pointer form): every ring address is
+//     (buffer resource in scalar registers, its base advanced on the scalar ALU once per k-step)  +  (one 32-bit byte
+//     offset per lane, constant for the whole product)  +  (an immediate)
+// so the loop holds no vector address arithmetic at all, and -- unlike gemm_nt_sbase -- the loads are builtins: the
+// compiler counts their waits itself, which makes the form safe where it spills around the call.  The base is a full
+// 64-bit address (no 2^31 limit on K x ld); past the end of K the refills read the last k-step again (no over-read).
+// Requirements: opI, opJ, ldI, ldJ wave-uniform AND the call reached through wave-uniform control flow only (scalar
+// branches): inside a divergent region the resources end up in vector registers and every load is waterfalled.
+// K a positive multiple of 4 PF.
+template <int NPI, int NPJ, int PF, int NACT = NPI, bool PEEL = true>
+__device__ __forceinline__ void gemm_nt_buf(WaveTile<NPI, NPJ> &t, const real *opI, int64_t ldI, const real *opJ, int64_t ldJ,
+                                            int K, int lane)
+{
+    static_assert(NACT >= 1 && NACT <= NPI, "active pairs");
+    constexpr int ES = (int)sizeof(real);
+    real2_t ra[PF][NACT], rb[PF][NPJ];
+    const int vI = (int)((2 * (lane & 15) + (int64_t)(lane >> 4) * ldI) * ES);
+    const int vJ = (int)((2 * (lane & 15) + (int64_t)(lane >> 4) * ldJ) * ES);
+    const int64_t sI = uniform_i64(4 * ldI * ES), sJ = uniform_i64(4 * ldJ * ES);
+    int64_t bI = uniform_i64(reinterpret_cast<int64_t>(opI)), bJ = uniform_i64(reinterpret_cast<int64_t>(opJ));
+    const int64_t eI = bI + (int64_t)(K / 4 - 1) * sI, eJ = bJ + (int64_t)(K / 4 - 1) * sJ;      // the last k-step
+    auto rsrc = [](int64_t base) {
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+    };
+#ifdef PMK_REAL_F32
+#define PMK_BUF_LD(r, voff, aux) __builtin_bit_cast(real2_t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, aux))
+#else
+#define PMK_BUF_LD(r, voff, aux) __builtin_bit_cast(real2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, aux))
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        const __amdgpu_buffer_rsrc_t rI = rsrc(bI), rJ = rsrc(bJ);
+#pragma unroll
+        for (int pi = 0; pi < NACT; ++pi) ra[s][pi] = PMK_BUF_LD(rI, vI + 32 * ES * pi, 0);
+#pragma unroll
+        for (int pj = 0; pj < NPJ; ++pj) rb[s][pj] = PMK_BUF_LD(rJ, vJ + 32 * ES * pj, 2);      // aux 2 = nt: the wave's own stream
+        bI = bI < eI ? bI + sI : eI;
+        bJ = bJ < eJ ? bJ + sJ : eJ;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto pass = [&]() {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const __amdgpu_buffer_rsrc_t rI = rsrc(bI), rJ = rsrc(bJ);
+#pragma unroll
+            for (int pi = 0; pi < NACT; ++pi) {
+#pragma unroll
+                for (int ei = 0; ei < 2; ++ei)
+#pragma unroll
+                    for (int pj = 0; pj < NPJ; ++pj)
+#pragma unroll
+                        for (int ej = 0; ej < 2; ++ej)
+                            t.f[2 * pi + ei][2 * pj + ej] =
+                                mfma_real(ra[s][pi][ei], rb[s][pj][ej], t.f[2 * pi + ei][2 * pj + ej]);
+                ra[s][pi] = PMK_BUF_LD(rI, vI + 32 * ES * pi, 0);
+                if (pi == NACT - 1) {
+#pragma unroll
+                    for (int pj = 0; pj < NPJ; ++pj) rb[s][pj] = PMK_BUF_LD(rJ, vJ + 32 * ES * pj, 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bI = bI < eI ? bI + sI : eI;
+            bJ = bJ < eJ ? bJ + sJ : eJ;
+        }
+    };
+    if (PEEL) pass();                     // see gemm_nt
+    for (int k0 = PEEL ? 4 * PF : 0; k0 < K; k0 += 4 * PF) pass();
+#undef PMK_BUF_LD
+}
+
 // In-register triangular solve of a 128-row tile, by block forward substitution over its four
 // 32-row blocks:   t  <-  -L^-1 t     (t: 128 x NJ*16, rows = the I dimension)
 //   u_s = Ninv_s (t_s + sum_{j<s} L[s][j] u_j),   Ninv_s = -(L[s][s])^-1  (negated inverted 32 x 32 blocks)

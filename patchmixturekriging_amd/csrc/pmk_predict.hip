@@ -93,6 +93,8 @@ __device__ __forceinline__ void strip_block_row(WaveTile<4, NPJW> &acc, const re
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #ifdef PMK_PRED_POINTER
         gemm_nt<4, NPJW, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
+#elif defined(PMK_PRED_BUF)
+        gemm_nt_buf<4, NPJW, PF_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
 #else
         gemm_nt_indexed<4, NPJW, PF_PRED, PFJ_PRED, NACT>(acc, Li, ld, V, TQ, i * TILE, lane);
 #endif
@@ -178,7 +180,13 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
                                                                double *__restrict__ u_out, double *__restrict__ v_out,
                                                                unsigned long long *__restrict__ clk)
 {
+    // the wave number as a scalar: everything decided per wave (is the wave active, which block-row variant) is then a
+    // scalar branch, and the buffer resources of the GEMM stay in scalar registers
+#ifdef PMK_PRED_SWAVE
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#endif
     // shader-clock probe: cycles and 10 ns ticks of the lifetime of workgroups 0..7, one per XCD (pmk_ctx_shader_clock)
     unsigned long long c0 = 0, r0 = 0;
     if (clk && blockIdx.x < 8 && threadIdx.x == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
