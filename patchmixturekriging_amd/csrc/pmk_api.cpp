@@ -631,6 +631,7 @@ int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)
     // everything already queued on the context's stream (the slabs still hold the previous factor, which earlier
     // predictions may be reading).
     const bool pipelined = c->pipeline_k1 && !c->timers && !m->split_mode && m->max_nt >= 3 && c->side_stream;
+    m->fuse_k1 = false;
     if (pipelined) {
         const int n_ev = m->max_nt;
         while ((int)c->col_ev.size() < n_ev) {
@@ -646,8 +647,15 @@ int pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2)
         }
         if ((rc = PMK_BY_DTYPE(m, launch_cholesky(m, c->stream, 0, m->P, c->col_ev.data(), n_ev)))) return rc;
     } else {
+        // Fused kernel-matrix build (PMK_FUSE_K1=0 turns it off): for the compact Spline34 profile in 2 or 3 dimensions K1
+        // writes the diagonal 128 x 128 tiles only, and the factorisation's step launches evaluate every tile below them at
+        // its one use instead of reading it from the slab (same kern_eval: the same bits).  Not on the split or queue paths.
+        const char *fe = std::getenv("PMK_FUSE_K1");
+        const bool fuse_env = !(fe && std::atoi(fe) == 0);
+        m->fuse_k1 = fuse_env && th->family == PMK_SPLINE34 && (m->D == 2 || m->D == 3) && !m->split_mode && !m->queue_mode &&
+                     m->max_nt >= 2;
         c->tic("kernel_matrix");
-        if ((rc = PMK_BY_DTYPE(m, launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P, -1)))) return rc;
+        if ((rc = PMK_BY_DTYPE(m, launch_kernel_matrix_slabs(m, *th, sigma2, c->stream, 0, m->P, m->fuse_k1 ? -2 : -1)))) return rc;
         c->toc("kernel_matrix");
         c->tic("cholesky");
         if ((rc = PMK_BY_DTYPE(m, launch_cholesky(m, c->stream, 0, m->P, nullptr, 0)))) return rc;

@@ -258,9 +258,15 @@ __global__ __launch_bounds__(256, 2) void chol_first_kernel(const PatchDesc *__r
 // substitution.  SPLIT: the deep product arrives as `nsplit` partial tiles instead (chol_partial_kernel).
 // Entered by all threads; contains one barrier (after the staging of the TRSM operands in `lds`); the caller
 // synchronises before `lds` is reused.
-template <int SPLIT, bool SC1 = false>
+// KD > 0 (fused kernel-matrix build, Spline34 in KD dimensions): the tile A[row, k] has never been written -- its
+// entries are evaluated here, at their one and only use, from the patch's coordinates (xs, SoA) with the same
+// kern_eval as K1: the same bits, without the write of the tile by K1 and its read here (the strictly lower 128 x 128
+// tiles are 7/8 of a 2000-point patch's kernel matrix).  Padding rows carry coordinates of 1e300, where the compact
+// profile is exactly 0 (a padded row never meets a padded column below the diagonal tiles).
+template <int SPLIT, bool SC1 = false, int KD = 0>
 __device__ __forceinline__ void block_row_update(const PatchDesc &pd, real *__restrict__ S, const real *__restrict__ ninv_p,
-                                                 int k, int row, real *lds, const real2_t *__restrict__ pt, int nsplit)
+                                                 int k, int row, real *lds, const real2_t *__restrict__ pt, int nsplit,
+                                                 const real *__restrict__ xs = nullptr, const pmk_kernel_desc *th = nullptr)
 {
     // the thread index is made opaque per call: called from inside a loop, the compiler otherwise hoists the 32
     // lane-dependent tile offsets (and the 64-bit addresses built on them) out of the loop, keeps them live across the
@@ -280,7 +286,7 @@ __device__ __forceinline__ void block_row_update(const PatchDesc &pd, real *__re
     // from HBM (first touch): its loads are issued before the operand staging so that the two latencies overlap
     // instead of adding up.
     WaveTile<4, 1> acc;   // I = the 128 columns of block column k, J = 32 rows
-    if (live) {
+    if (KD == 0 && live) {
 #pragma unroll
         for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
@@ -294,8 +300,46 @@ __device__ __forceinline__ void block_row_update(const PatchDesc &pd, real *__re
     __builtin_amdgcn_sched_barrier(0);      // keep the tile loads ahead of the staging loads
     // the TRSM operands (off-diagonal 32-blocks of L[kk] and the four -D^-1 blocks) go to LDS once per workgroup
     stage_tri_operands(lds, S + c0 + c0 * ld, ld, ninv_p + (int64_t)k * (4 * SB * SB), tid, 256);
+    if (KD > 0 && live) {
+        // K[rows, block column k]: the lane's two rows against its 32 columns, under the latency of the staging loads
+        constexpr int DD = KD > 0 ? KD : 1;
+        real xr[2][DD];
+#pragma unroll
+        for (int d = 0; d < DD; ++d) {
+            const real2_t v = *reinterpret_cast<const real2_t *>(xs + (int64_t)d * ld + r0 + 2 * (lane & 15));
+            xr[0][d] = v[0];
+            xr[1][d] = v[1];
+        }
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {          // static accumulator indices: fully unrolled (64 evaluations)
+                real xc[2][DD];
+#pragma unroll
+                for (int d = 0; d < DD; ++d) {
+                    const real2_t v = *reinterpret_cast<const real2_t *>(xs + (int64_t)d * ld + c0 + 32 * pi + 2 * frag_irow(lane >> 4, q));
+                    xc[0][d] = v[0];
+                    xc[1][d] = v[1];
+                }
+#pragma unroll
+                for (int ei = 0; ei < 2; ++ei)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        acc.f[2 * pi + ei][e][q] = kern_eval<DD, PMK_SPLINE34, real>(*th, xr[e], xc[ei]);
+            }
+    }
     __syncthreads();
-    if (!live) return;
+    if (!live) {
+        if (KD > 0) {
+            // nobody has written these rows of the slab (K1 left the tiles below the diagonal alone): the identity padding's
+            // zeros, which the look-ahead of the last diagonal tile reads, are put down here
+#pragma unroll
+            for (int fi = 0; fi < 8; ++fi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) put2<SC1>(out + tile_i(fi, lane, q) * ld, real2_t{0, 0});
+        }
+        return;
+    }
 #pragma unroll
     for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
@@ -484,14 +528,15 @@ __device__ __forceinline__ void step_slot(int nslots, int G, int &slot, int &bx)
 // applies block column k itself (128 deep) and carries on as above -- except that the forward-solve right-hand side is
 // not carried along (z comes from the separate solve sweeps of that path).
 // ---------------------------------------------------------------------------------------------
-template <int SPLIT>
+template <int SPLIT, int KD = 0>
 __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__restrict__ descs,
                                                            const int32_t *__restrict__ order, int nactive, int G,
                                                            int launch, int max_nt, real *__restrict__ A,
                                                            real *__restrict__ ninv, const real *__restrict__ y,
                                                            real *__restrict__ z, int32_t *__restrict__ info,
                                                            const real2_t *__restrict__ partial, int nsplit,
-                                                           unsigned long long *__restrict__ clk)
+                                                           unsigned long long *__restrict__ clk,
+                                                           const real *__restrict__ x, pmk_kernel_desc th)
 {
     __shared__ real lds[TRI_LDS_DOUBLES];
     int slot, bx;
@@ -527,8 +572,9 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
     }
 #endif
     PMK_STAMP(2);
-    block_row_update<SPLIT>(pd, S, ninv + pd.ioff, k, k + 1 + bx, lds,
-                            SPLIT ? partial + (((int64_t)slot * (G + 1) + bx) * nsplit) * PARTIAL_TILE : nullptr, nsplit);
+    block_row_update<SPLIT, false, KD>(pd, S, ninv + pd.ioff, k, k + 1 + bx, lds,
+                                       SPLIT ? partial + (((int64_t)slot * (G + 1) + bx) * nsplit) * PARTIAL_TILE : nullptr, nsplit,
+                                       KD ? x + pd.xoff : nullptr, &th);
     PMK_STAMP(3);
 #ifdef PMK_TRACE
     if (launch == PMK_TRACE && tid == 0 && blockIdx.x < TRACE_MAX_WG)      // shader cycles of wave 0's block-row phase
@@ -1338,13 +1384,19 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
             hipLaunchKernelGGL(chol_partial_kernel, dim3((unsigned)(nactive * tiles * nsplit)), dim3(256), 0, s,
                                m->d_desc, m->d_order, nactive, G, nsplit, l, m->max_nt, (const real *)m->d_a,
                                (real2_t *)m->d_partial);
-            hipLaunchKernelGGL(chol_step_kernel<1>, dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
+            hipLaunchKernelGGL((chol_step_kernel<1, 0>), dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
                                m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,
-                               (const real2_t *)m->d_partial, nsplit, m->ctx->d_clk);
+                               (const real2_t *)m->d_partial, nsplit, m->ctx->d_clk, (const real *)m->d_x, m->th);
         } else {
-            hipLaunchKernelGGL(chol_step_kernel<0>, dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
-                               m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,
-                               (const real2_t *)nullptr, 1, m->ctx->d_clk);
+#define PMK_STEP(KD_)                                                                                                        \
+            hipLaunchKernelGGL((chol_step_kernel<0, KD_>), dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,  \
+                               m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,  \
+                               (const real2_t *)nullptr, 1, m->ctx->d_clk, (const real *)m->d_x, m->th)
+            // fused kernel-matrix build (pmk_model_fit decides): the strictly lower tiles are evaluated at their first use
+            if (m->fuse_k1 && m->D == 2) PMK_STEP(2);
+            else if (m->fuse_k1 && m->D == 3) PMK_STEP(3);
+            else PMK_STEP(0);
+#undef PMK_STEP
         }
         if (int rc = ev_end(l)) return rc;
     }

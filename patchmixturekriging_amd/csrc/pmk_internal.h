@@ -105,6 +105,7 @@ struct pmk_model {
     // split path (few, large patches: the deep products of a step are cut along K over several workgroups and the two
     // triangular solves run block by block over many workgroups): chosen at creation from P and the tile counts
     bool split_mode = false;
+    bool fuse_k1 = false;               // this fit evaluates the strictly lower kernel-matrix tiles inside the factorisation
     // task-queue form of the batched factorisation (one launch for all block columns, pmk_chol.hip): per-XCD task lists
     // and the scheduling block (list heads, error word, per-patch dependency flags), built at the first fit
     std::vector<int32_t> order;         // host copy of d_order

@@ -26,7 +26,14 @@ __global__ __launch_bounds__(256) void kmat_slab_kernel(const PatchDesc *__restr
     const real sigma2 = (real)sigma2_d;
     const int nt64 = pd.ld / 64;
     int ti, tj;
-    if (stage < 0) {
+    if (stage == -2) {
+        // fused fit: only the diagonal 128 x 128 tiles (potrf and look-ahead read them from the slab); the tiles below are
+        // evaluated by the factorisation at their first use.  Three 64 x 64 tiles per diagonal tile.
+        const int c = blockIdx.x / 3, r = blockIdx.x - 3 * c;
+        if (c >= pd.nt) return;
+        ti = 2 * c + (r > 0);
+        tj = 2 * c + (r > 1);
+    } else if (stage < 0) {
         const int ntiles = nt64 * (nt64 + 1) / 2;
         const int t = blockIdx.x;
         if (t >= ntiles) return;
@@ -78,7 +85,7 @@ static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double s
                          int stage)
 {
     const int nt64 = m->max_nt * (TILE / 64);
-    dim3 grid((unsigned)(stage < 0 ? nt64 * (nt64 + 1) / 2 : 2 * nt64), (unsigned)np);
+    dim3 grid((unsigned)(stage == -2 ? 3 * m->max_nt : stage < 0 ? nt64 * (nt64 + 1) / 2 : 2 * nt64), (unsigned)np);
     if (th.family == PMK_SPLINE34)
         hipLaunchKernelGGL((kmat_slab_kernel<D, PMK_SPLINE34>), grid, dim3(256), 0, s, m->d_desc + p0, (const real *)m->d_x, (real *)m->d_a, th, sigma2, stage, m->max_nt);
     else

@@ -1244,3 +1244,23 @@ def test_bench_launched_plainly_with_two_ranks(extra):
     assert d["config"]["exchange"] in ("torch", "allgather-torch")
     if extra[:1] == ["--exchange"]:
         assert d["config"]["shard_queries"] == "replicated" and d["exchange_bytes"]["received_per_rank"][0] > 0
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_fused_kernel_matrix_build_is_bit_identical(monkeypatch, D):
+    # Spline34 in 2 / 3 dimensions: K1 writes the diagonal 128 x 128 tiles only and the step launches evaluate the tiles
+    # below them at their first use (pmk_chol.hip, block_row_update<.., KD>); PMK_FUSE_K1=0 is the unfused build + read.
+    # Ragged sizes around the tile edge (padding rows, single-tile patches): L, the inverted blocks and c must not differ
+    rng = np.random.default_rng(5 + D)
+    sizes = [1, 129, 257, 300, 640, 1000, 1111, 127, 128, 900, 513, 2000]
+    Xs = [rng.uniform(-4, 4, (n, D)) for n in sizes]
+    ys = [np.sin(x[:, 0]) * np.cos(0.5 * x[:, 1]) for x in Xs]
+    th = pmk.Spline34KernelType(1 / 3.0)
+    got = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("PMK_FUSE_K1", fuse)
+        model, cs, info = pmk.fit_patches(Xs, ys, th, 1e-5)
+        assert np.all(info == 0)
+        got.append([(cs[r], model.get(r, M.GET_L), model.get(r, M.GET_LINV_DIAG)) for r in range(len(sizes))])
+    for (c0, L0, N0), (c1, L1, N1) in zip(*got):
+        assert np.array_equal(c0, c1) and np.array_equal(L0, L1) and np.array_equal(N0, N1)
