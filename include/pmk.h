@@ -159,6 +159,11 @@ int  pmk_model_fit(pmk_model *m, const pmk_kernel_desc *th, double sigma2);
 int  pmk_model_info(pmk_model *m, int32_t *info);
 /* replace the resident targets (same sizes) */
 int  pmk_model_set_targets(pmk_model *m, const double *const *y);
+/* Per-point addend of the kernel's DIAGONAL: the next fits use K[i][i] = k(x_i, x_i) + diag[r][i] (+ sigma2).  This is
+ * what the reference's AdaptiveKernelDPPType / AdaptiveKernelMultiWarpDPPType add where p == q (src/RKHS/kernel.jl:70-75,
+ * 102-110: 1 + g(p)^2, resp. 1 + self_gain sum a_m |w_m(p)|), the rest of those kernels being a stationary kernel on
+ * positions + appended warp values.  diag = NULL clears it.  Blocks. */
+int  pmk_model_set_diag(pmk_model *m, const double *const *diag);
 enum { PMK_GET_C = 0, PMK_GET_L = 1, PMK_GET_K = 2, PMK_GET_LINV_DIAG = 3 };
 /* pull c_set[r] (n), L_set[r] (n x n lower, strict upper zero), U_set[r] (n x n, K without
  * noise, rebuilt on demand), or the negated inverses of the 32 x 32 diagonal blocks of L
@@ -212,6 +217,8 @@ int  pmk_query_item_buffers(pmk_query *q, void **u_dev, void **v_dev);
  * which evaluates queryinner! for them and sends (u, v) back into the requester's item buffers.
  * requests of the sorted items [first, first + n) -> DEVICE arrays xq_dev [n x D point-major], region_dev [n] */
 int  pmk_query_export_requests(pmk_query *q, int64_t first, int64_t n, double *xq_dev, int32_t *region_dev);
+/* per-query addend of k(xq, xq) in the predictive variance (the same diagonal term for a query point; NULL clears) */
+int  pmk_query_set_diag(pmk_query *q, const double *diag);
 /* a planned batch of n explicit (point, region) items, one per point (host or device pointers); every region must
  * lie in this model's leaves (-3 otherwise).  Follow with pmk_query_items + pmk_query_export_results. */
 int  pmk_query_create_items(pmk_model *m, int64_t n, const double *xq, const int32_t *region, pmk_query **out);

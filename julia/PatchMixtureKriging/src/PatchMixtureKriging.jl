@@ -103,14 +103,38 @@ struct AdaptiveKernelMultiWarpType{KT,T}
     warpfuncs::Vector{Function}
     a::Vector{T}
 end
-const WarpedKernel = Union{AdaptiveKernelType,FastAdaptiveKernelType,AdaptiveKernelMultiWarpType}
+# the DPP variants (declarations.jl:115-118, 141-149; kernel.jl:70-89, 102-113): the same warped kernel where p != q, and a
+# point-dependent term where p == q (1 + g(p)Â², resp. 1 + self_gain Î£ aâ‚˜ |wâ‚˜(p)|) -- on the device a per-point addend of
+# the kernel's diagonal (pmk_model_set_diag / pmk_query_set_diag)
+struct AdaptiveKernelDPPType{KT}
+    canonical_params::KT
+    warpfunc::Function
+end
+struct AdaptiveKernelMultiWarpDPPType{KT,T}
+    canonical_params::KT
+    warpfuncs::Vector{Function}
+    a::Vector{T}
+    self_gain::T
+end
+const DPPKernel = Union{AdaptiveKernelDPPType,AdaptiveKernelMultiWarpDPPType}
+const WarpedKernel = Union{AdaptiveKernelType,FastAdaptiveKernelType,AdaptiveKernelMultiWarpType,AdaptiveKernelDPPType,
+                           AdaptiveKernelMultiWarpDPPType}
 canonical(Î¸::AdaptiveKernelType) = Î¸.canonical_params
 canonical(Î¸::FastAdaptiveKernelType) = Î¸.canonical_kernel
 canonical(Î¸::AdaptiveKernelMultiWarpType) = Î¸.canonical_params
+canonical(Î¸::AdaptiveKernelDPPType) = Î¸.canonical_params
+canonical(Î¸::AdaptiveKernelMultiWarpDPPType) = Î¸.canonical_params
 desc(Î¸::WarpedKernel) = desc(canonical(Î¸))
 features(Î¸::AdaptiveKernelType, x) = [Float64(Î¸.warpfunc(x))]
+features(Î¸::AdaptiveKernelDPPType, x) = [Float64(Î¸.warpfunc(x))]
 features(Î¸::FastAdaptiveKernelType, x) = [Float64(Î¸.s[i] * Î¸.warpfuncs[i](x)) for i = 1:length(Î¸.warpfuncs)]
 features(Î¸::AdaptiveKernelMultiWarpType, x) = [Float64(sqrt(Î¸.a[m]) * Î¸.warpfuncs[m](x)) for m = 1:length(Î¸.warpfuncs)]
+features(Î¸::AdaptiveKernelMultiWarpDPPType, x) = [Float64(sqrt(Î¸.a[m]) * Î¸.warpfuncs[m](x)) for m = 1:length(Î¸.warpfuncs)]
+# the diagonal term of a kernel at the points X: nothing for every kernel but the DPP variants
+diagaddend(Î¸, X) = nothing
+diagaddend(Î¸::AdaptiveKernelDPPType, X) = Float64[Î¸.warpfunc(x)^2 for x in X]
+diagaddend(Î¸::AdaptiveKernelMultiWarpDPPType, X) =
+    Float64[Î¸.self_gain * sum(Î¸.a[m] * abs(Î¸.warpfuncs[m](x)) for m = 1:length(Î¸.warpfuncs)) for x in X]
 
 # ------------------------------------------------------------------------------------------ helpers
 """array2matrix (src/misc/utilities.jl:25-36): Vector{Vector{T}} -> D x N matrix"""
@@ -152,6 +176,15 @@ function constructkernelmatrix(X, Î¸)::Matrix{Float64}
     check(ccall((:pmk_kernel_matrix, libpmk), Cint,
         (Ptr{Cvoid}, Ref{KernelDesc}, Cint, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64),
         context(), d, D, n, Xm, n, C_NULL, K, n), "constructkernelmatrix")
+    g = diagaddend(Î¸, X)
+    if g !== nothing                                    # kernel.jl:74, 108: where p == q (by distance: duplicates too)
+        for i = 1:n, j = 1:i
+            if i == j || X[i] == X[j]
+                K[i, j] += g[i]
+                i == j || (K[j, i] += g[i])
+            end
+        end
+    end
     return K
 end
 """constructkernelmatrix(X, Z, Î¸) (src/RKHS/RKHS.jl:95-110)"""
@@ -162,6 +195,12 @@ function constructkernelmatrix(X::Vector{Vector{T}}, Z::Vector{Vector{T}}, Î¸)::
     check(ccall((:pmk_kernel_matrix, libpmk), Cint,
         (Ptr{Cvoid}, Ref{KernelDesc}, Cint, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Int64),
         context(), d, D, n, Xm, m, Zm, K, n), "constructkernelmatrix")
+    g = diagaddend(Î¸, X)
+    if g !== nothing
+        for i = 1:n, j = 1:m
+            X[i] == Z[j] && (K[i, j] += g[i])
+        end
+    end
     return K
 end
 evalkernel(p::Vector{T}, q::Vector{T}, Î¸) where T = constructkernelmatrix([p], [q], Î¸)[1, 1]
@@ -388,7 +427,8 @@ end
 the device patch by patch when they are first indexed (LazyFactors); store_factors = true pulls all of them at once."""
 function fitmixtureGP!(Î·::MixtureGPType{T}, y_parts::Vector{Vector{T}}, Î¸, ÏƒÂ²; store_factors::Bool = false) where T
     P = length(Î·.X_parts)
-    Xm = [pack(X) for X in Î·.X_parts]; ys = [Vector{Float64}(y) for y in y_parts]
+    # positions, or positions + warp values for a warp-feature kernel (the tree is built on the positions alone)
+    Xm = [kpack(Î¸, X) for X in Î·.X_parts]; ys = [Vector{Float64}(y) for y in y_parts]
     n = Int64[size(x, 2) for x in Xm]; D = size(Xm[1], 1)
     for r = 1:P
         @assert length(ys[r]) == n[r]                      # mixtureGP.jl:298
@@ -398,13 +438,26 @@ function fitmixtureGP!(Î·::MixtureGPType{T}, y_parts::Vector{Vector{T}}, Î¸, ÏƒÂ
         Î·.model = C_NULL; Î·.handle[] = C_NULL
     end
     h = Ref{Ptr{Cvoid}}(C_NULL); info = Vector{Int32}(undef, P); d = Ref(desc(Î¸))
-    GC.@preserve Xm ys begin
-        rc = ccall((:pmk_fit_batched, libpmk), Cint,
-            (Ptr{Cvoid}, Ref{KernelDesc}, Float64, Cint, Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}},
-             Ref{Ptr{Cvoid}}, Ptr{Ptr{Float64}}, Ptr{Int32}),
-            context(), d, ÏƒÂ², D, P, n, [pointer(x) for x in Xm], [pointer(y) for y in ys], h, C_NULL, info)
+    gs = [diagaddend(Î¸, X) for X in Î·.X_parts]          # the DPP kernels' own diagonal term, else nothing
+    if gs[1] === nothing
+        GC.@preserve Xm ys begin
+            rc = ccall((:pmk_fit_batched, libpmk), Cint,
+                (Ptr{Cvoid}, Ref{KernelDesc}, Float64, Cint, Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}},
+                 Ref{Ptr{Cvoid}}, Ptr{Ptr{Float64}}, Ptr{Int32}),
+                context(), d, ÏƒÂ², D, P, n, [pointer(x) for x in Xm], [pointer(y) for y in ys], h, C_NULL, info)
+        end
+        check(rc, "fitmixtureGP!")
+    else
+        GC.@preserve Xm ys gs begin
+            check(ccall((:pmk_model_create, libpmk), Cint,
+                (Ptr{Cvoid}, Cint, Int64, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ref{Ptr{Cvoid}}),
+                context(), D, P, n, [pointer(x) for x in Xm], [pointer(y) for y in ys], h), "pmk_model_create")
+            check(ccall((:pmk_model_set_diag, libpmk), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}), h[], [pointer(g) for g in gs]),
+                  "pmk_model_set_diag")
+            check(ccall((:pmk_model_fit, libpmk), Cint, (Ptr{Cvoid}, Ref{KernelDesc}, Float64), h[], d, ÏƒÂ²), "pmk_model_fit")
+            check(ccall((:pmk_model_info, libpmk), Cint, (Ptr{Cvoid}, Ptr{Int32}), h[], info), "pmk_model_info")
+        end
     end
-    check(rc, "fitmixtureGP!")
     Î·.model = h[]
     Î·.handle[] = h[]
     empty!(Î·.U_set.cache); empty!(Î·.L_set.cache)
@@ -427,12 +480,14 @@ function querymixtureGP!(Yq::Vector{T}, Vq::Vector{T}, Xq::Vector{Vector{T}}, Î·
                          radius::T, Î´::T, Î¸, ÏƒÂ², weight_Î¸, debug_vars::MixtureGPDebugType{T};
                          debug_flag = false)::Nothing where T
     Î·.model == C_NULL && throw(PMKError("fitmixtureGP! must run before querymixtureGP!"))
-    Nq = length(Xq); Xm = pack(Xq)
+    Nq = length(Xq); Xm = kpack(Î¸, Xq)                         # positions (+ warp values): the tree uses the positions
     resize!(Yq, Nq); resize!(Vq, Nq)                          # mixtureGP.jl:179-180
     check(ccall((:pmk_model_set_bsp, libpmk), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), Î·.model, native(root), 0), "pmk_model_set_bsp")
     q = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:pmk_query_create, libpmk), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ref{Ptr{Cvoid}}), Î·.model, Nq, Xm, q), "pmk_query_create")
     try
+        gq = diagaddend(Î¸, Xq)
+        gq === nothing || check(ccall((:pmk_query_set_diag, libpmk), Cint, (Ptr{Cvoid}, Ptr{Float64}), q[], gq), "pmk_query_set_diag")
         check(ccall((:pmk_query_plan, libpmk), Cint, (Ptr{Cvoid}, Float64, Float64), q[], radius, Î´), "pmk_query_plan")
         check(ccall((:pmk_query_items, libpmk), Cint, (Ptr{Cvoid}, Ref{KernelDesc}), q[], Ref(desc(Î¸))), "pmk_query_items")
         check(ccall((:pmk_query_mix, libpmk), Cint, (Ptr{Cvoid}, Ref{KernelDesc}, Int64, Int64), q[], Ref(desc(weight_Î¸)), 0, Nq), "pmk_query_mix")

@@ -76,11 +76,15 @@ def lib():
                                       _ip, _dp, _dp, _bp]
     L.pmko_fit_patch.restype = C.c_int
     L.pmko_fit_patch.argtypes = [_kp, C.c_int, C.c_int64, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp]
+    L.pmko_fit_patch_diag.restype = C.c_int
+    L.pmko_fit_patch_diag.argtypes = [_kp, C.c_int, C.c_int64, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]
     L.pmko_fit_rkhs.restype = C.c_int
     L.pmko_fit_rkhs.argtypes = [_kp, C.c_int, C.c_int64, _dp, _dp, C.c_double, _dp]
     L.pmko_query_rkhs.argtypes = [_kp, C.c_int, C.c_int64, _dp, _dp, C.c_int64, _dp, _dp]
     L.pmko_queryinner.argtypes = [_kp, C.c_int, C.c_int64, _dp, _dp, _dp, C.c_int64, _dp,
                                   C.c_double, _dp, _dp, _dp]
+    L.pmko_queryinner_diag.argtypes = [_kp, C.c_int, C.c_int64, _dp, _dp, _dp, C.c_int64, _dp, C.c_double,
+                                       C.c_double, _dp, _dp, _dp]
     L.pmko_query_mixture.restype = C.c_int64
     L.pmko_query_mixture.argtypes = [C.c_void_p, _kp, _kp, _ip, C.POINTER(_dp), C.POINTER(_dp),
                                      C.POINTER(_dp), C.c_int64, _dp, C.c_double, C.c_double,
@@ -196,8 +200,9 @@ class BSP:
         return reg[:k].copy(), ts, zs, keep.astype(bool)
 
 
-def fit_patch(th, X, y, sigma2, want_K=False):
-    """one iteration of fitmixtureGP! -> dict(info, c_lu, L, c_chol[, K])"""
+def fit_patch(th, X, y, sigma2, want_K=False, diag=None):
+    """one iteration of fitmixtureGP! -> dict(info, c_lu, L, c_chol[, K]); diag: the DPP kernels' point-dependent
+    diagonal term (part of K), X then being positions + warp values"""
     X = _pts(X)
     n, D = X.shape
     y = np.ascontiguousarray(y, dtype=np.float64)
@@ -205,8 +210,9 @@ def fit_patch(th, X, y, sigma2, want_K=False):
     c_ch = np.empty(n)
     L = np.empty((n, n), order="F")
     K = np.empty((n, n), order="F") if want_K else None
-    info = lib().pmko_fit_patch(C.byref(th), D, n, _d(X), _d(y), sigma2,
-                                _d(K) if want_K else None, _d(c_lu), _d(L), _d(c_ch))
+    dg = None if diag is None else np.ascontiguousarray(diag, dtype=np.float64)
+    info = lib().pmko_fit_patch_diag(C.byref(th), D, n, _d(X), _d(y), sigma2, None if dg is None else _d(dg),
+                                     _d(K) if want_K else None, _d(c_lu), _d(L), _d(c_ch))
     out = dict(info=info, c_lu=c_lu, L=L, c_chol=c_ch)
     if want_K:
         out["K"] = K
@@ -233,7 +239,7 @@ def query_rkhs(th, X, c, Xq):
     return Yq
 
 
-def queryinner(th, X, c, L, xq, min_v=1e-12):
+def queryinner(th, X, c, L, xq, min_v=1e-12, qdiag=0.0):
     X = _pts(X)
     n, D = X.shape
     xq = np.ascontiguousarray(xq, dtype=np.float64)
@@ -241,8 +247,8 @@ def queryinner(th, X, c, L, xq, min_v=1e-12):
     L = np.asfortranarray(L, dtype=np.float64)
     work = np.empty(n)
     mu, var = C.c_double(), C.c_double()
-    lib().pmko_queryinner(C.byref(th), D, n, _d(X), _d(c), _d(L), n, _d(xq), min_v, _d(work),
-                          C.byref(mu), C.byref(var))
+    lib().pmko_queryinner_diag(C.byref(th), D, n, _d(X), _d(c), _d(L), n, _d(xq), float(qdiag), min_v, _d(work),
+                               C.byref(mu), C.byref(var))
     return mu.value, var.value
 
 

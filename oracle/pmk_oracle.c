@@ -551,12 +551,18 @@ static void trsv_lower_t(int64_t n, const double *L, int64_t ldl, double *x)
     }
 }
 
-/* one iteration of fitmixtureGP! src/RKHS/mixtureGP.jl:92-115 */
-int pmko_fit_patch(const pmko_kernel *th, int D, int64_t n, const double *X, const double *y,
-                   double sigma2, double *K_out, double *c_lu, double *L, double *c_chol)
+/* one iteration of fitmixtureGP! src/RKHS/mixtureGP.jl:92-115.
+ * diag (may be NULL): the point-dependent diagonal term of the reference's DPP kernels -- evalkernel(p, p, theta) =
+ * 1 + g(p) for AdaptiveKernelDPPType / AdaptiveKernelMultiWarpDPPType (src/RKHS/kernel.jl:70-75, 102-110), whose
+ * off-diagonal part is a stationary kernel on positions + warp values (X is then the augmented point set): part of K,
+ * added before the noise. */
+int pmko_fit_patch_diag(const pmko_kernel *th, int D, int64_t n, const double *X, const double *y,
+                        double sigma2, const double *diag, double *K_out, double *c_lu, double *L, double *c_chol)
 {
     int info = 0;
     pmko_kernel_matrix(th, D, n, X, L, n);                             /* :98 */
+    if (diag)
+        for (int64_t i = 0; i < n; ++i) L[i + i * n] += diag[i];       /* kernel.jl:74 / :108 */
     if (K_out) memcpy(K_out, L, sizeof(double) * (size_t)(n * n));    /* :99 U_set */
     for (int64_t i = 0; i < n; ++i) L[i + i * n] += sigma2;            /* :102-104 */
     if (c_lu) {                                                        /* :106 c = U\y */
@@ -577,6 +583,12 @@ int pmko_fit_patch(const pmko_kernel *th, int D, int64_t n, const double *X, con
         trsv_lower_t(n, L, n, c_chol);
     }
     return info;
+}
+
+int pmko_fit_patch(const pmko_kernel *th, int D, int64_t n, const double *X, const double *y,
+                   double sigma2, double *K_out, double *c_lu, double *L, double *c_chol)
+{
+    return pmko_fit_patch_diag(th, D, n, X, y, sigma2, NULL, K_out, c_lu, L, c_chol);
 }
 
 /* fitRKHS! src/RKHS/RKHS.jl:195-217 */
@@ -606,10 +618,21 @@ void pmko_query_rkhs(const pmko_kernel *th, int D, int64_t n, const double *X, c
     }
 }
 
-/* queryinner! src/RKHS/mixtureGP.jl:296-316 */
+/* queryinner! src/RKHS/mixtureGP.jl:296-316; qdiag = the DPP kernels' diagonal term at the query point (0 otherwise) */
+void pmko_queryinner_diag(const pmko_kernel *th, int D, int64_t n, const double *X, const double *c,
+                          const double *L, int64_t ldl, const double *xq, double qdiag, double min_v,
+                          double *kq, double *mu, double *var);
+
 void pmko_queryinner(const pmko_kernel *th, int D, int64_t n, const double *X, const double *c,
                      const double *L, int64_t ldl, const double *xq, double min_v,
                      double *kq, double *mu, double *var)
+{
+    pmko_queryinner_diag(th, D, n, X, c, L, ldl, xq, 0.0, min_v, kq, mu, var);
+}
+
+void pmko_queryinner_diag(const pmko_kernel *th, int D, int64_t n, const double *X, const double *c,
+                          const double *L, int64_t ldl, const double *xq, double qdiag, double min_v,
+                          double *kq, double *mu, double *var)
 {
     for (int64_t i = 0; i < n; ++i) kq[i] = pmko_kernel_eval(th, D, xq, X + i * D);   /* :302-305 */
     double s = 0.0;
@@ -618,7 +641,9 @@ void pmko_queryinner(const pmko_kernel *th, int D, int64_t n, const double *X, c
     trsv_lower(n, L, ldl, kq);                                                        /* :311 */
     double vv = 0.0;
     for (int64_t i = 0; i < n; ++i) vv = (i == 0) ? kq[i] * kq[i] : vv + kq[i] * kq[i];
-    double vq = pmko_kernel_eval(th, D, xq, xq) - vv;                                  /* :312 */
+    double kself = pmko_kernel_eval(th, D, xq, xq);
+    if (qdiag != 0.0) kself = kself + qdiag;                                           /* kernel.jl:74 / :108 */
+    double vq = kself - vv;                                                            /* :312 */
     *var = (vq < min_v) ? min_v : vq;
 }
 

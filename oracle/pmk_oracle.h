@@ -94,6 +94,8 @@ int64_t   pmko_bsp_neighbours(const pmko_bsp *t, const double *p, double radius,
  * or -1 for a singular LU. */
 int pmko_fit_patch(const pmko_kernel *th, int D, int64_t n, const double *X, const double *y,
                    double sigma2, double *K_out, double *c_lu, double *L, double *c_chol);
+int pmko_fit_patch_diag(const pmko_kernel *th, int D, int64_t n, const double *X, const double *y,
+                        double sigma2, const double *diag, double *K_out, double *c_lu, double *L, double *c_chol);
 
 /* fitRKHS! (RKHS.jl:182-217): c = (K + sigma2 I) \ y by LU */
 int pmko_fit_rkhs(const pmko_kernel *th, int D, int64_t n, const double *X, const double *y,
@@ -106,6 +108,9 @@ void pmko_query_rkhs(const pmko_kernel *th, int D, int64_t n, const double *X, c
 void pmko_queryinner(const pmko_kernel *th, int D, int64_t n, const double *X, const double *c,
                      const double *L, int64_t ldl, const double *xq, double min_v,
                      double *work, double *mu, double *var);
+void pmko_queryinner_diag(const pmko_kernel *th, int D, int64_t n, const double *X, const double *c,
+                          const double *L, int64_t ldl, const double *xq, double qdiag, double min_v,
+                          double *kq, double *mu, double *var);
 
 /* querymixtureGP! (mixtureGP.jl:159-294).  Model = per-region arrays.
  * Optional debug outputs (NULL to skip): home[Nq]; nb_offsets[Nq+1] + nb_regions/nb_t

@@ -8,7 +8,7 @@ fallback -- without the library the operators raise.
 """
 from ._lib import PmkError, build, lib                                              # noqa: F401
 from .context import Comm, Context, comm_unique_id, default_context, set_device, shard_segments                            # noqa: F401
-from .kernels import (AdaptiveKernelMultiWarpType, AdaptiveKernelType, BrownianBridge10, BrownianBridge1eps, BrownianBridge20,        # noqa: F401
+from .kernels import (AdaptiveKernelDPPType, AdaptiveKernelMultiWarpDPPType, AdaptiveKernelMultiWarpType, AdaptiveKernelType, BrownianBridge10, BrownianBridge1eps, BrownianBridge20,        # noqa: F401
                       BrownianBridge2eps, BrownianBridgeKernelType, BrownianBridgeSemiInfDomain,
                       FastAdaptiveKernelType, GaussianKernel1DType, ModulatedSqExpKernelType, RationalQuadraticKernelType,
                       Spline12KernelType, Spline32KernelType, Spline34KernelType, StationaryKernelType,

@@ -78,6 +78,8 @@ SIGNATURES = {
     "pmk_model_fit": (C.c_int, [_vp, _kp, C.c_double]),
     "pmk_model_info": (C.c_int, [_vp, _i32p]),
     "pmk_model_set_targets": (C.c_int, [_vp, _dpp]),
+    "pmk_model_set_diag": (C.c_int, [_vp, C.c_void_p]),
+    "pmk_query_set_diag": (C.c_int, [_vp, _dp]),
     "pmk_model_get": (C.c_int, [_vp, C.c_int64, C.c_int, _dp, C.c_int64]),
     "pmk_model_num_patches": (C.c_int64, [_vp]),
     "pmk_model_destroy": (None, [_vp]),

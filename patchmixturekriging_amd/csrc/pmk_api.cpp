@@ -474,7 +474,7 @@ void pmk_model_destroy(pmk_model *m)
     dev_free(m->d_order);
     dev_free(m->d_sched);
     dev_free(m->d_sched_init);
-    for (void **p : {&m->d_qtasks, &m->d_x, &m->d_y, &m->d_z, &m->d_c, &m->d_a, &m->d_inv, &m->d_strip, &m->d_partial, &m->d_solve_part}) {
+    for (void **p : {&m->d_qtasks, &m->d_diag, &m->d_x, &m->d_y, &m->d_z, &m->d_c, &m->d_a, &m->d_inv, &m->d_strip, &m->d_partial, &m->d_solve_part}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -594,6 +594,42 @@ int pmk_model_create_ex(pmk_ctx *ctx, int D, int64_t P, const int64_t *n, const 
         return -100;
     }
     *out = m;
+    return 0;
+}
+
+int pmk_model_set_diag(pmk_model *m, const double *const *diag)
+{
+    if (!m) { set_error("pmk_model_set_diag: model is NULL"); return -1; }
+    PMK_HIP(hipSetDevice(m->ctx->device));
+    PMK_HIP(hipStreamSynchronize(m->ctx->stream));
+    m->fitted = false;
+    if (!diag) {
+        if (m->d_diag) (void)hipFree(m->d_diag);
+        m->d_diag = nullptr;
+        return 0;
+    }
+    if (!m->d_diag && hipMalloc(&m->d_diag, m->esz * (size_t)std::max<int64_t>(m->tot_y, 1)) != hipSuccess) {
+        set_error("pmk_model_set_diag: out of device memory");
+        return -100;
+    }
+    std::vector<double> hd((size_t)m->tot_y, 0.0);
+    for (int64_t r = 0; r < m->P; ++r) {
+        if (!diag[r]) { set_error("pmk_model_set_diag: the addends of patch %lld are NULL", (long long)r); return -2; }
+        std::memcpy(hd.data() + m->desc[(size_t)r].yoff, diag[r], sizeof(double) * (size_t)m->desc[(size_t)r].n);
+    }
+    return upload_real(m, m->d_diag, 0, hd.data(), hd.size());
+}
+
+int pmk_query_set_diag(pmk_query *q, const double *diag)
+{
+    if (!q) { set_error("pmk_query_set_diag: query is NULL"); return -1; }
+    pmk_ctx *c = q->m->ctx;
+    PMK_HIP(hipSetDevice(c->device));
+    PMK_HIP(hipStreamSynchronize(c->stream));
+    dev_free(q->d_qdiag);
+    if (!diag || q->Nq == 0) return 0;
+    if (dev_alloc(&q->d_qdiag, q->Nq)) return -100;
+    PMK_HIP(hipMemcpy(q->d_qdiag, diag, sizeof(double) * (size_t)q->Nq, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -750,6 +786,11 @@ int pmk_model_get(pmk_model *m, int64_t patch, int what, double *out, int64_t ld
             PMK_HIP(hipMemcpy2DAsync(out, sizeof(double) * ld, dK, sizeof(double) * d.n, sizeof(double) * d.n, (size_t)d.n,
                                      hipMemcpyDeviceToHost, c->stream));
         PMK_HIP(hipStreamSynchronize(c->stream));
+        if (!rc && m->d_diag) {                   // the kernel's own diagonal term is part of K (not the noise)
+            std::vector<double> hd((size_t)d.n);
+            if (int rc2 = download_real_2d(m, hd.data(), d.n, m->d_diag, d.yoff, d.ld, d.n, 1, c->stream)) return rc2;
+            for (int64_t i = 0; i < d.n; ++i) out[i + i * ld] += hd[(size_t)i];
+        }
         return rc;
     }
     case PMK_GET_LINV_DIAG:
@@ -884,7 +925,11 @@ int pmk_model_set_bsp(pmk_model *m, const pmk_bsp *bsp, int64_t leaf_base)
 {
     if (!m || !bsp) { set_error("pmk_model_set_bsp: NULL argument"); return -1; }
     const BspArrays &t = bsp->t;
-    if (t.D != m->D) { set_error("pmk_model_set_bsp: tree dimension %d != model dimension %d", t.D, m->D); return -2; }
+    // The tree may live in the first t.D of the model's D coordinates (warp-feature kernels: the partition is built on the
+    // positions, the kernel runs on positions + appended warp values).  The normals are padded with zeros: v . x, the foot
+    // points z = p + t v and their distances then come out bit for bit as in t.D dimensions (the extra products are exact
+    // zeros), so leaf ids, neighbour lists and t values are those of the tree's own space.
+    if (t.D > m->D) { set_error("pmk_model_set_bsp: tree dimension %d > model dimension %d", t.D, m->D); return -2; }
     if (leaf_base < 0 || leaf_base + m->P > t.P) {
         set_error("pmk_model_set_bsp: leaves [%lld, %lld) outside the tree's %lld leaves", (long long)leaf_base,
                   (long long)(leaf_base + m->P), (long long)t.P);
@@ -892,11 +937,14 @@ int pmk_model_set_bsp(pmk_model *m, const pmk_bsp *bsp, int64_t leaf_base)
     }
     PMK_HIP(hipSetDevice(m->ctx->device));
     dev_free(m->d_hv); dev_free(m->d_hc); dev_free(m->d_pre);
-    if (dev_alloc(&m->d_hv, (t.P - 1) * t.D) || dev_alloc(&m->d_hc, t.P - 1) || dev_alloc(&m->d_pre, t.P - 1)) return -100;
+    if (dev_alloc(&m->d_hv, (t.P - 1) * m->D) || dev_alloc(&m->d_hc, t.P - 1) || dev_alloc(&m->d_pre, t.P - 1)) return -100;
     std::vector<int32_t> pre32((size_t)(t.P - 1));
     for (size_t i = 0; i < pre32.size(); ++i) pre32[i] = (int32_t)t.pre[i];
     if (t.P > 1) {
-        PMK_HIP(hipMemcpy(m->d_hv, t.v.data(), sizeof(double) * t.v.size(), hipMemcpyHostToDevice));
+        std::vector<double> hv((size_t)((t.P - 1) * m->D), 0.0);
+        for (int64_t h = 0; h < t.P - 1; ++h)
+            for (int d = 0; d < t.D; ++d) hv[(size_t)(h * m->D + d)] = t.v[(size_t)(h * t.D + d)];
+        PMK_HIP(hipMemcpy(m->d_hv, hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice));
         PMK_HIP(hipMemcpy(m->d_hc, t.c.data(), sizeof(double) * t.c.size(), hipMemcpyHostToDevice));
         PMK_HIP(hipMemcpy(m->d_pre, pre32.data(), sizeof(int32_t) * pre32.size(), hipMemcpyHostToDevice));
     }
@@ -910,7 +958,7 @@ int pmk_model_set_bsp(pmk_model *m, const pmk_bsp *bsp, int64_t leaf_base)
 void pmk_query_destroy(pmk_query *q)
 {
     if (!q) return;
-    dev_free(q->d_xq); dev_free(q->d_home); dev_free(q->d_cnt); dev_free(q->d_qoff);
+    dev_free(q->d_xq); dev_free(q->d_qdiag); dev_free(q->d_home); dev_free(q->d_cnt); dev_free(q->d_qoff);
     dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
     dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_roff);
     dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w); dev_free(q->d_yq); dev_free(q->d_vq); dev_free(q->d_flag);

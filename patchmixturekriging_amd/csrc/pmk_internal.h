@@ -93,6 +93,7 @@ struct pmk_model {
     size_t esz = 8;
     void *d_x = nullptr;                // SoA coordinates
     void *d_y = nullptr;                // targets (padded with 0)
+    void *d_diag = nullptr;             // per-point addend of the kernel's diagonal (pmk_model_set_diag), or null
     void *d_z = nullptr;                // L^-1 y
     void *d_c = nullptr;                // weights
     void *d_a = nullptr;                // slabs
@@ -140,6 +141,7 @@ struct pmk_query {
     int64_t nq_cap = 0;             // capacity of the per-point buffers below (grow only)
     int *d_flag = nullptr;          // device scratch flag (region range check of explicit items)
     double *d_xq = nullptr;         // point-major D x Nq
+    double *d_qdiag = nullptr;      // per-query addend of k(xq, xq) (pmk_query_set_diag), or null
     int32_t *d_home = nullptr;      // Nq
     int32_t *d_cnt = nullptr;       // Nq : items per query (neighbours + 1)
     int64_t *d_qoff = nullptr;      // Nq+1

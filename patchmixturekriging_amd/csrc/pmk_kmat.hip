@@ -20,7 +20,7 @@ namespace PMK_NS {
 template <int D, int FAM>
 __global__ __launch_bounds__(256) void kmat_slab_kernel(const PatchDesc *__restrict__ descs, const real *__restrict__ x,
                                                         real *__restrict__ A, pmk_kernel_desc th, double sigma2_d, int stage,
-                                                        int max_nt)
+                                                        int max_nt, const real *__restrict__ dg)
 {
     const PatchDesc pd = descs[blockIdx.y];
     const real sigma2 = (real)sigma2_d;
@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void kmat_slab_kernel(const PatchDesc *__restr
             real v;
             if (i < pd.n && j < pd.n) {
                 v = (i >= j) ? kern_eval<D, FAM, real>(th, xi[a], xj[b]) : kern_eval<D, FAM, real>(th, xj[b], xi[a]);
-                if (i == j) v = v + sigma2;
+                if (i == j) {
+                    if (dg) v = v + dg[pd.yoff + i];      // the kernel's own point-dependent diagonal term (pmk_model_set_diag)
+                    v = v + sigma2;
+                }
             } else {
                 v = (i == j) ? (real)1 : (real)0;
             }
@@ -87,9 +90,9 @@ static int launch_slab_D(const pmk_model *m, const pmk_kernel_desc &th, double s
     const int nt64 = m->max_nt * (TILE / 64);
     dim3 grid((unsigned)(stage == -2 ? 3 * m->max_nt : stage < 0 ? nt64 * (nt64 + 1) / 2 : 2 * nt64), (unsigned)np);
     if (th.family == PMK_SPLINE34)
-        hipLaunchKernelGGL((kmat_slab_kernel<D, PMK_SPLINE34>), grid, dim3(256), 0, s, m->d_desc + p0, (const real *)m->d_x, (real *)m->d_a, th, sigma2, stage, m->max_nt);
+        hipLaunchKernelGGL((kmat_slab_kernel<D, PMK_SPLINE34>), grid, dim3(256), 0, s, m->d_desc + p0, (const real *)m->d_x, (real *)m->d_a, th, sigma2, stage, m->max_nt, (const real *)m->d_diag);
     else
-        hipLaunchKernelGGL((kmat_slab_kernel<D, 0>), grid, dim3(256), 0, s, m->d_desc + p0, (const real *)m->d_x, (real *)m->d_a, th, sigma2, stage, m->max_nt);
+        hipLaunchKernelGGL((kmat_slab_kernel<D, 0>), grid, dim3(256), 0, s, m->d_desc + p0, (const real *)m->d_x, (real *)m->d_a, th, sigma2, stage, m->max_nt, (const real *)m->d_diag);
     PMK_HIP(hipGetLastError());
     return 0;
 }

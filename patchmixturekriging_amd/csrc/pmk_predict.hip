@@ -178,7 +178,8 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
                                                                int64_t strip_stride, pmk_kernel_desc th,
                                                                uint32_t *__restrict__ sync_cnt, int round_base, double min_v,
                                                                double *__restrict__ u_out, double *__restrict__ v_out,
-                                                               unsigned long long *__restrict__ clk)
+                                                               unsigned long long *__restrict__ clk,
+                                                               const double *__restrict__ qdiag)
 {
     // the wave number as a scalar: everything decided per wave (is the wave active, which block-row variant) is then a
     // scalar branch, and the buffer resources of the GEMM stay in scalar registers
@@ -355,6 +356,8 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
                 for (int d = 0; d < D; ++d) qe[d] = pk[(c * D + d) * PRED_THREADS];
                 const real kself = kern_eval<D, FAM, real>(th, qe, qe);
                 double var = (double)kself - (double)b;               // mixtureGP.jl:312
+                // the kernel's own diagonal term at the query point (pmk_query_set_diag: DPP kernels, kernel.jl:74, 108)
+                if (qdiag) var = ((double)kself + qdiag[item_query[sorted_item[tk.first + col]]]) - (double)b;
                 var = var < min_v ? min_v : var;                     // clamp(..., min_v, Inf)
                 u_out[tk.first + col] = (double)a;
                 v_out[tk.first + col] = var;
@@ -485,11 +488,11 @@ int launch_items(pmk_query *q, const pmk_kernel_desc &th, hipStream_t s)
         if (s34)                                                                                                       \
             hipLaunchKernelGGL((predict_strip_kernel<DD, PMK_SPLINE34>), dim3((unsigned)q->strip_grid), dim3(PRED_THREADS), 0, s, \
                                m->d_desc, (real *)m->d_x, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
-                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->min_v, q->d_u, q->d_v, m->ctx->d_clk);  \
+                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->min_v, q->d_u, q->d_v, m->ctx->d_clk, q->d_qdiag);  \
         else                                                                                                           \
             hipLaunchKernelGGL((predict_strip_kernel<DD, 0>), dim3((unsigned)q->strip_grid), dim3(PRED_THREADS), 0, s,  \
                                m->d_desc, (real *)m->d_x, (real *)m->d_a, (real *)m->d_inv, (real *)m->d_c, d_tasks, (int)q->ntasks, q->d_sorted_item,  \
-                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->min_v, q->d_u, q->d_v, m->ctx->d_clk);  \
+                               q->d_item_query, q->d_xq, (real *)m->d_strip, stride, th, q->d_sync, (int)q->round_base, q->min_v, q->d_u, q->d_v, m->ctx->d_clk, q->d_qdiag);  \
         break;
         PMK_CASE(1) PMK_CASE(2) PMK_CASE(3) PMK_CASE(4)
 #undef PMK_CASE

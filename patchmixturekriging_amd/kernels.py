@@ -182,6 +182,27 @@ class AdaptiveKernelMultiWarpType(_WarpedKernel):      # declarations.jl:130-135
         return np.array([[r[m] * float(w(x)) for m, w in enumerate(self.warpfuncs)] for x in X])
 
 
+class AdaptiveKernelDPPType(AdaptiveKernelType):       # declarations.jl (AdaptiveKernelDPPType), kernel.jl:70-89
+    """k(p, q) = canonical(sqrt(|p - q|² + (g(p) - g(q))²)) for p != q and 1 + g(p)² where p == q (norm(p - q) < 2 eps):
+    the warped canonical kernel plus a point-dependent diagonal term.  On the device: warp feature + per-point diagonal
+    addend g(p)² (pmk_model_set_diag / pmk_query_set_diag; the canonical profiles are 1 at 0)."""
+
+    def diag_addend(self, X):
+        return np.array([float(self.warpfunc(x)) ** 2 for x in as_points(X)])
+
+
+class AdaptiveKernelMultiWarpDPPType(AdaptiveKernelMultiWarpType):    # kernel.jl:102-113
+    """as AdaptiveKernelMultiWarpType off the diagonal; 1 + self_gain * sum_m a_m |w_m(p)| where p == q"""
+
+    def __init__(self, canonical_params, warpfuncs, a, self_gain):
+        super().__init__(canonical_params, warpfuncs, a)
+        self.self_gain = float(self_gain)
+
+    def diag_addend(self, X):
+        return np.array([self.self_gain * sum(self.a[m] * abs(float(w(x))) for m, w in enumerate(self.warpfuncs))
+                         for x in as_points(X)])
+
+
 def as_points(X):
     """Vector{Vector{T}} -> (N, D) C-contiguous float64 (= the D x N packing of array2matrix)"""
     X = np.ascontiguousarray(X, dtype=np.float64)

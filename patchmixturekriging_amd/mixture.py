@@ -94,6 +94,18 @@ class DeviceModel:
         PA = _dp * self.P
         _lib.check(self.ctx.L.pmk_model_set_targets(self.h, PA(*[_d(y) for y in ys])), "pmk_model_set_targets")
 
+    def set_diag(self, diag_parts):
+        """pmk_model_set_diag: per-point addend of the kernel's diagonal for the next fits (None clears it)"""
+        if diag_parts is None:
+            _lib.check(self.ctx.L.pmk_model_set_diag(self.h, None), "pmk_model_set_diag")
+            return
+        ds = [np.ascontiguousarray(d, dtype=np.float64) for d in diag_parts]
+        for d, n in zip(ds, self.n):
+            if len(d) != n:
+                raise ValueError("one addend per point")
+        PA = _dp * self.P
+        _lib.check(self.ctx.L.pmk_model_set_diag(self.h, PA(*[_d(d) for d in ds])), "pmk_model_set_diag")
+
     def fit(self, theta, sigma2):
         """enqueue kernel build + Cholesky + solves for every patch"""
         d = theta.desc()
@@ -138,6 +150,16 @@ class DeviceQuery:
         _lib.check(model.ctx.L.pmk_query_create(model.h, self.Nq, _d(self.Xq), C.byref(h)), "pmk_query_create")
         self.h = h
         self.L = model.ctx.L
+
+    def set_diag(self, diag):
+        """pmk_query_set_diag: per-query addend of k(xq, xq) in the predictive variance (None clears it)"""
+        if diag is None:
+            _lib.check(self.L.pmk_query_set_diag(self.h, None), "pmk_query_set_diag")
+            return
+        d = np.ascontiguousarray(diag, dtype=np.float64)
+        if len(d) != self.Nq:
+            raise ValueError("one addend per query point")
+        _lib.check(self.L.pmk_query_set_diag(self.h, _d(d)), "pmk_query_set_diag")
 
     @classmethod
     def from_items(cls, model, n, xq_ptr, region_ptr):
@@ -228,9 +250,19 @@ class DeviceQuery:
                     item_v=v[:n])
 
 
+def kernel_points(theta, X):
+    """the points the device evaluates the kernel on: X itself, or X with the warp features appended for the
+    closure-carrying kernels (kernels.py: AdaptiveKernelType & co.)"""
+    return theta.augment(X) if getattr(theta, "warped", False) else as_points(X)
+
+
 def fit_patches(X_parts, y_parts, theta, sigma2, ctx=None, dtype="f64"):
-    """create + fit + info + weights: the batched path behind fitmixtureGP! and fitRKHS!"""
-    model = DeviceModel(X_parts, y_parts, ctx, dtype=dtype)
+    """create + fit + info + weights: the batched path behind fitmixtureGP! and fitRKHS!.  X_parts are POSITIONS: for a
+    warp-feature kernel the model is built on the augmented points, and a DPP kernel's point-dependent diagonal term goes
+    in as the per-point addend (pmk_model_set_diag)."""
+    model = DeviceModel([kernel_points(theta, x) for x in X_parts], y_parts, ctx, dtype=dtype)
+    if hasattr(theta, "diag_addend"):
+        model.set_diag([theta.diag_addend(x) for x in X_parts])
     model.fit(theta, sigma2)
     info = model.info()
     cs = [model.get(r, GET_C) for r in range(model.P)]
@@ -300,8 +332,10 @@ def querymixtureGP_(Yq, Vq, Xq, eta, root, levels, radius, delta, theta, sigma2,
         raise _lib.PmkError("fitmixtureGP_ must run before querymixtureGP_")
     Xq = as_points(Xq)
     model = eta._model
-    model.set_bsp(root, 0)
-    q = DeviceQuery(model, Xq)
+    model.set_bsp(root, 0)          # the tree lives in the positions; a warp-feature kernel's model has more coordinates
+    q = DeviceQuery(model, kernel_points(theta, Xq))
+    if hasattr(theta, "diag_addend"):
+        q.set_diag(theta.diag_addend(Xq))
     q.plan(radius, delta)
     q.items(theta)
     q.mix(weight_theta)
@@ -349,6 +383,15 @@ def querymixtureGP(Xq, eta, root, levels, radius, delta, theta, sigma2, weight_t
 def queryinner(xq, X, theta, c, L):
     """queryinner(xq, X, θ, c, L) -> (μ, σ²)   (mixtureGP.jl:296-320): the factors are uploaded
     (pmk_model_load) and one strip of the prediction kernel runs against them"""
-    model = DeviceModel.from_factors([X], [c], [L])
-    mu, var = model.queryinner(0, theta, np.asarray(xq, dtype=np.float64)[None, :])
+    xq = np.asarray(xq, dtype=np.float64)[None, :]
+    model = DeviceModel.from_factors([kernel_points(theta, X)], [c], [L])
+    if hasattr(theta, "diag_addend"):
+        # k(xq, xq) carries the kernel's own diagonal term: unclamped variance from the device, term added, then the clamp
+        Xk = kernel_points(theta, xq)
+        mu, var = np.empty(1), np.empty(1)
+        d = theta.desc()
+        _lib.check(model.ctx.L.pmk_model_queryinner_ex(model.h, 0, C.byref(d), 1, _d(Xk), -np.inf, _d(mu), _d(var)),
+                   "pmk_model_queryinner_ex")
+        return float(mu[0]), float(max(var[0] + theta.diag_addend(xq)[0], 1e-12))
+    mu, var = model.queryinner(0, theta, kernel_points(theta, xq))
     return float(mu[0]), float(var[0])

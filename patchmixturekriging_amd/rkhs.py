@@ -21,6 +21,32 @@ def _kernel_points(theta, X):
     return theta.augment(X) if getattr(theta, "warped", False) else as_points(X)
 
 
+def _add_dpp_diagonal(K, theta, X, Z):
+    """AdaptiveKernelDPPType / AdaptiveKernelMultiWarpDPPType return 1 + g(p) where p == q (kernel.jl:74, 108: norm(p - q)
+    < 2 eps, i.e. the same point) instead of the canonical value at 0: added here, on the host matrix"""
+    X = as_points(X)
+    g = theta.diag_addend(X)
+    if Z is None:
+        K[np.diag_indices(X.shape[0])] += g
+        # duplicates of a point at other indices get the term too (the reference tests the distance, not the index);
+        # K[i, j] = evalkernel(X[i], X[j]) for i >= j, mirrored: the row point's term
+        seen = {}
+        for i, x in enumerate(map(tuple, X)):
+            for j in seen.get(x, ()):
+                K[i, j] += g[i]
+                K[j, i] += g[i]
+            seen.setdefault(x, []).append(i)
+        return K
+    Z = as_points(Z)
+    where = {}
+    for j, z in enumerate(map(tuple, Z)):
+        where.setdefault(z, []).append(j)
+    for i, x in enumerate(map(tuple, X)):
+        for j in where.get(x, ()):
+            K[i, j] += g[i]
+    return K
+
+
 def constructkernelmatrix(X, theta_or_Z, theta=None):
     """constructkernelmatrix(X, θ) -> n x n (RKHS.jl:4-34, exactly symmetric; RKHS.jl:132-167 for
     FastAdaptiveKernelType, whose w_X table is refreshed as the reference does);
@@ -30,6 +56,7 @@ def constructkernelmatrix(X, theta_or_Z, theta=None):
         theta, Z = theta_or_Z, None
     else:
         Z = _kernel_points(theta, theta_or_Z)
+    X_pos, Z_pos = X, (None if Z is None else theta_or_Z)
     if Z is None and hasattr(theta, "update_w_X"):
         theta.update_w_X(X)
     X = _kernel_points(theta, X)
@@ -42,6 +69,8 @@ def constructkernelmatrix(X, theta_or_Z, theta=None):
     ctx = default_context()
     _lib.check(ctx.L.pmk_kernel_matrix(ctx.h, C.byref(d), D, n, _d(X), m, _d(Z) if Z is not None else None,
                                        _d(K), n), "constructkernelmatrix")
+    if hasattr(theta, "diag_addend"):
+        _add_dpp_diagonal(K, theta, X_pos, Z_pos)
     return K
 
 
@@ -77,7 +106,7 @@ def fitRKHS_(eta, y):
     from .mixture import fit_patches
     if isinstance(eta.theta, (list, tuple)):
         raise TypeError("fitRKHS! is defined for one kernel (RKHS.jl:182-217); per-centre kernels only have query!")
-    model, cs, info = fit_patches([_kernel_points(eta.theta, eta.X)], [y], eta.theta, eta.sigma2)
+    model, cs, info = fit_patches([eta.X], [y], eta.theta, eta.sigma2)        # warp features / diagonal term: fit_patches
     if info[0] != 0:
         raise np.linalg.LinAlgError("matrix is not positive definite; leading minor %d" % info[0])
     eta.c[:] = cs[0]
@@ -135,6 +164,8 @@ class GPQuery:
         if Xk.shape[0] != len(self.c):
             raise ValueError("length(c) == length(X)")
         self.model = DeviceModel([Xk], [np.zeros(len(self.c))])          # the targets play no role: only L is used ...
+        if hasattr(theta, "diag_addend"):
+            self.model.set_diag([theta.diag_addend(X)])
         self.model.fit(theta, float(sigma2))
         info = self.model.info()
         if info[0] != 0:
@@ -144,11 +175,14 @@ class GPQuery:
 
     def many(self, Xq):
         """(means, variances) of a batch of query points"""
+        Xpos = as_points(Xq)
         Xq = _kernel_points(self.theta, Xq)
         mu, var = np.empty(Xq.shape[0]), np.empty(Xq.shape[0])
         d = self.theta.desc()
         _lib.check(self.model.ctx.L.pmk_model_queryinner_ex(self.model.h, 0, C.byref(d), Xq.shape[0], _d(Xq), -np.inf, _d(mu),
                                                             _d(var)), "evalqueryGP!")
+        if hasattr(self.theta, "diag_addend"):
+            var = var + self.theta.diag_addend(Xpos)      # k(xq, xq) of a DPP kernel (the variance is not clamped here)
         return mu, var
 
     def __call__(self, xq):

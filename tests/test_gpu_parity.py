@@ -1264,3 +1264,90 @@ def test_fused_kernel_matrix_build_is_bit_identical(monkeypatch, D):
         got.append([(cs[r], model.get(r, M.GET_L), model.get(r, M.GET_LINV_DIAG)) for r in range(len(sizes))])
     for (c0, L0, N0), (c1, L1, N1) in zip(*got):
         assert np.array_equal(c0, c1) and np.array_equal(L0, L1) and np.array_equal(N0, N1)
+
+
+def test_dpp_kernels_and_warp_kernels_in_the_mixture_path():
+    """SURVEY 8(f) rank 4, remainder: AdaptiveKernelDPPType (kernel.jl:70-89) and AdaptiveKernelMultiWarpDPPType (:102-113)
+    = the warped canonical kernel off the diagonal + a point-dependent term where p == q, and warp-feature kernels in
+    fitmixtureGP! / querymixtureGP! (the tree is built on the positions, the kernel runs on positions + warp values).
+    Against the reference's formulas written out in numpy, and against the oracle given the augmented points + the term."""
+    rng = np.random.Generator(np.random.PCG64(53))
+    canon, ocanon = pmk.Spline34KernelType(0.35), O.kernel(O.SPLINE34, 0.35)
+    w1 = lambda x: np.sin(2 * x[0]) * x[1]            # noqa: E731
+    w2 = lambda x: 0.5 * np.cos(x[0] + x[1])           # noqa: E731
+    a, gain = np.array([0.5, 2.0]), 0.3
+
+    def k_dpp(p, q):                                   # kernel.jl:70-89
+        if np.linalg.norm(p - q) < 2 * np.finfo(float).eps:
+            return 1.0 + w1(p) ** 2
+        return O.profile(ocanon, np.sqrt(np.dot(p - q, p - q) + (w1(p) - w1(q)) ** 2))
+
+    def k_mdpp(p, q):                                  # kernel.jl:102-113, 119-139
+        if np.linalg.norm(p - q) < 2 * np.finfo(float).eps:
+            return 1.0 + gain * sum(a[m] * abs(w(p)) for m, w in enumerate([w1, w2]))
+        return O.profile(ocanon, np.sqrt(np.dot(p - q, p - q) + sum(a[m] * (w(p) - w(q)) ** 2 for m, w in enumerate([w1, w2]))))
+
+    n = 200
+    X = rng.uniform(-1, 1, (n, 2))
+    X[17] = X[4]                                       # a duplicated point: the term applies by distance, not by index
+    y = np.sin(3 * X[:, 0]) + X[:, 1]
+    for th, kf in ((pmk.AdaptiveKernelDPPType(canon, w1), k_dpp),
+                   (pmk.AdaptiveKernelMultiWarpDPPType(canon, [w1, w2], a, gain), k_mdpp)):
+        R = np.array([[kf(X[max(i, j)], X[min(i, j)]) for j in range(n)] for i in range(n)])
+        K = pmk.constructkernelmatrix(X, th)
+        assert np.array_equal(K, K.T) and np.abs(K - R).max() <= 1e-14
+        assert K[17, 4] == K[4, 4] and K[4, 4] > 1.0
+        Z = np.concatenate([X[:5], rng.uniform(-1, 1, (7, 2))])
+        Kz = pmk.constructkernelmatrix(X, Z, th)       # RKHS.jl:95-110: evalkernel(X[i], Z[j])
+        Rz = np.array([[kf(X[i], Z[j]) for j in range(len(Z))] for i in range(n)])
+        assert np.abs(Kz - Rz).max() <= 1e-14
+    # single problem with the DPP kernel: fitRKHS!, then setupGPquery's variance against the formula (querying.jl:43-79)
+    Xs = np.delete(X, 17, axis=0); ys = np.delete(y, 17)
+    th = pmk.AdaptiveKernelDPPType(canon, w1)
+    Rs = np.array([[k_dpp(Xs[max(i, j)], Xs[min(i, j)]) for j in range(n - 1)] for i in range(n - 1)])
+    eta = pmk.RKHSProblemType(np.zeros(n - 1), Xs, th, 1e-4)
+    pmk.fitRKHS_(eta, ys)
+    U = Rs + 1e-4 * np.eye(n - 1)
+    assert np.linalg.norm(U @ eta.c - ys) / (np.linalg.norm(U) * np.linalg.norm(eta.c) + np.linalg.norm(ys)) <= 1e-12
+    fq = pmk.setupGPquery(eta.c, Xs, th, 1e-4)
+    Xq = rng.uniform(-1, 1, (40, 2))
+    mu, var = fq.many(Xq)
+    for j in range(40):
+        kq = np.array([k_dpp(Xq[j], x) for x in Xs])
+        assert abs(mu[j] - kq @ eta.c) <= 1e-9 * max(1, abs(kq @ eta.c))
+        assert abs(var[j] - (k_dpp(Xq[j], Xq[j]) - kq @ np.linalg.solve(U, kq))) <= 1e-9
+    # the oracle, given positions + warp value and the term, agrees with the formula (CPU restatement of the same kernels)
+    f = O.fit_patch(ocanon, th.augment(Xs), ys, 1e-4, want_K=True, diag=th.diag_addend(Xs))
+    assert np.abs(f["K"] - Rs).max() <= 1e-14
+    # ---- the mixture path with warp-feature kernels: plain adaptive and DPP
+    N, levels, eps, radius, delta, sigma2 = 2400, 4, 0.3, 0.5, 1e-5, 1e-4
+    Xm = np.stack([rng.uniform(-5, 5, N), rng.uniform(-10, 10, N)], 1)
+    ym = np.sin(Xm[:, 0]) * np.cos(0.3 * Xm[:, 1])
+    Xqm = np.stack([rng.uniform(-5, 5, 500), rng.uniform(-10, 10, 500)], 1)
+    wm = lambda x: 0.8 * np.sin(0.7 * x[0]) + 0.1 * x[1]      # noqa: E731
+    cm, ocm = pmk.Spline34KernelType(1 / 4.0), O.kernel(O.SPLINE34, 1 / 4.0)
+    wth, owth = pmk.Spline34KernelType(1 / radius), O.kernel(O.SPLINE34, 1 / radius)
+    root, _, _ = pmk.setuppartition(Xm, levels)
+    X_set, X_set_inds, _, _ = pmk.organizetrainingsets(root, levels, Xm, eps)
+    ob = O.BSP(Xm, levels)
+    for th in (pmk.AdaptiveKernelType(cm, wm), pmk.AdaptiveKernelDPPType(cm, wm)):
+        dpp = hasattr(th, "diag_addend")
+        eta = pmk.MixtureGPType(X_set, pmk.fetchhyperplanes(root))
+        pmk.fitmixtureGP_(eta, [ym[i] for i in X_set_inds], th, sigma2)
+        Yq, Vq, dbg = pmk.querymixtureGP(Xqm, eta, root, levels, radius, delta, th, sigma2, wth, debug_flag=True)
+        fits = [O.fit_patch(ocm, th.augment(xs), ym[i], sigma2, want_K=True, diag=th.diag_addend(xs) if dpp else None)
+                for xs, i in zip(X_set, X_set_inds)]
+        for r in (0, len(X_set) - 1):
+            assert np.abs(eta.U_set[r] - fits[r]["K"]).max() <= 1e-13 and np.abs(eta.L_set[r] - fits[r]["L"]).max() <= 1e-8
+        for j in range(len(Xqm)):
+            h = ob.findpartition(Xqm[j])                                  # the tree sees positions only
+            reg, ts, _, keep = ob.neighbours(Xqm[j], radius, delta, h)
+            assert dbg.p_region_ind_set[j] == h and np.array_equal(dbg.region_inds_set[j], reg)
+            assert np.array_equal(dbg.ts_set[j][keep], ts[keep])
+            xa = th.augment(Xqm[j][None, :])[0]
+            qd = th.diag_addend(Xqm[j][None, :])[0] if dpp else 0.0
+            uv = [O.queryinner(ocm, th.augment(X_set[r]), fits[r]["c_lu"], fits[r]["L"], xa, qdiag=qd) for r in list(reg) + [h]]
+            w = np.array([O.profile(owth, abs(t)) for t in ts[keep]] + [1.0])
+            w = w / w.sum()
+            yj, vj = w @ np.array([u for u, _ in uv]), w @ (np.array([v for _, v in uv]) * w)
+            assert abs(Yq[j] - yj) <= 1e-7 * max(1, abs(yj)) and abs(Vq[j] - vj) <= 1e-9 + 1e-5 * vj

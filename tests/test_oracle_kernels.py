@@ -90,3 +90,23 @@ def test_bb_rank_deficiency_with_endpoints(golden):
     x = np.linspace(0, 1, 15)
     K = O.kernel_matrix(O.kernel(O.BB10, 1.0), x)
     assert np.linalg.matrix_rank(K) == 13 == int(golden("ibb1d.npz")["rank_with_endpoints"])
+
+
+def test_dpp_diagonal_term_in_the_oracle():
+    """pmko_fit_patch_diag / pmko_queryinner_diag: the DPP kernels' point-dependent diagonal term (kernel.jl:70-75, 102-110)
+    is part of K (before the noise) and of k(xq, xq); against numpy on a small case"""
+    rng = np.random.default_rng(3)
+    n = 40
+    X = rng.uniform(0, 1, (n, 3))                      # positions + one warp value
+    y = np.sin(4 * X[:, 0])
+    g = rng.uniform(0.1, 0.9, n)
+    th = O.kernel(O.SPLINE34, 1.2)
+    f0 = O.fit_patch(th, X, y, 1e-3, want_K=True)
+    f = O.fit_patch(th, X, y, 1e-3, want_K=True, diag=g)
+    assert np.array_equal(f["K"], f0["K"] + np.diag(g))
+    U = f["K"] + 1e-3 * np.eye(n)
+    assert np.abs(f["L"] @ f["L"].T - U).max() < 1e-13 and np.abs(U @ f["c_lu"] - y).max() < 1e-10
+    xq = rng.uniform(0, 1, 3)
+    mu0, v0 = O.queryinner(th, X, f["c_lu"], f["L"], xq, min_v=-np.inf)
+    mu1, v1 = O.queryinner(th, X, f["c_lu"], f["L"], xq, min_v=-np.inf, qdiag=0.25)
+    assert mu0 == mu1 and abs((v1 - v0) - 0.25) < 1e-15
