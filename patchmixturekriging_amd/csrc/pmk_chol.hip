@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
     if (launch == PMK_TRACE && lane == 0 && blockIdx.x < TRACE_MAX_WG)
         atomicMax(&g_trace[TRACE_WORDS * blockIdx.x + 6], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
-    if (bx != 0) return;
+    if (bx != 0 || SPLIT) return;      // split steps: the next diagonal tile is factorised beside the next step's products
     // ================= critical workgroup: look-ahead + potrf of diagonal tile k + 1 =================
     __syncthreads();
     PMK_STAMP(4);
@@ -889,15 +889,33 @@ __global__ __launch_bounds__(256, 2) void chol_queue_kernel(const PatchDesc *__r
 // tiles x K chunks), and writes the partial tiles; chol_step_kernel<1> sums them.  Tile layout in memory = the
 // accumulator layout ([wave][fragment][register][lane] pairs), so stores and loads are 1 KB coalesced per wave.
 // ---------------------------------------------------------------------------------------------
+// The first `npot` workgroups of the launch do something else: the diagonal tile that the PREVIOUS split step left to be
+// factorised (its look-ahead partial tiles are in that step's buffer, its block row is final) -- look-ahead sum, the
+// block column just made, potrf -- beside this step's products, which do not depend on it (they read block columns
+// < k; the step kernel that follows needs both).  Inside the step kernel that chain (~200 us, one workgroup, the rest
+// of the chip idle) was most of a step of a single large problem.
 __global__ __launch_bounds__(256, 2) void chol_partial_kernel(const PatchDesc *__restrict__ descs,
                                                               const int32_t *__restrict__ order, int nactive, int G,
-                                                              int nsplit, int launch, int max_nt, const real *__restrict__ A,
-                                                              real2_t *__restrict__ partial)
+                                                              int nsplit, int launch, int max_nt, real *__restrict__ A,
+                                                              real2_t *__restrict__ partial, int npot, int pot_G,
+                                                              int pot_nsplit, const real2_t *__restrict__ pot_partial,
+                                                              real *__restrict__ ninv, const real *__restrict__ y,
+                                                              real *__restrict__ z, int32_t *__restrict__ info)
 {
+    __shared__ real lds[TRI_LDS_DOUBLES];
+    if ((int)blockIdx.x < npot) {
+        const int slot = blockIdx.x, pid = order[slot];
+        const PatchDesc pd = descs[pid];
+        const int k = (launch - 1) - (max_nt - pd.nt);           // the block column of the previous step
+        lookahead_potrf<1>(pd, A + pd.aoff, ninv + pd.ioff, y + pd.yoff, z + pd.yoff, info + pid, k, lds,
+                           pot_partial + (((int64_t)slot * (pot_G + 1) + pot_G) * pot_nsplit) * PARTIAL_TILE, pot_nsplit);
+        return;
+    }
     // (patch slot, tile, K chunk) straight from the block id: consecutive blocks = the chunks of one tile, then the next
     // tile of the same patch -- spread over all XCDs (this path exists because there are too few patches to fill them)
     const int tiles = G + 1;
-    const int idx = blockIdx.x;
+    const int idx = (int)blockIdx.x - npot;
+    if (idx >= nactive * tiles * nsplit) return;
     const int slot = idx / (tiles * nsplit), rem = idx - slot * (tiles * nsplit);
     const int t = rem / nsplit, sp = rem - t * nsplit;
     const PatchDesc pd = descs[order[slot]];
@@ -1359,6 +1377,32 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
         return 0;
     };
     const int l0 = 0;
+    // split path: K chunks so that ONE patch's tiles x chunks would fill the chip (a function of the step alone, not of the
+    // number of patches: the summation order of a tile, hence every bit of the factor, is then the same whether a patch
+    // is factorised alone or next to others -- sharded and single models stay bit-identical); a chunk is at least two
+    // block columns deep; 64-way: the serial sum in the combine costs more than it buys
+    auto nsplit_of = [&](int l, int G) {
+        return (m->split_mode && l >= 4) ? std::max(1, std::min(std::min(16, l / 2), (want_wg + G) / (G + 1))) : 1;
+    };
+    // the partial tiles of a step live in one half of the buffer, those of the next step in the other: the diagonal tile a
+    // split step leaves behind is factorised by the first workgroups of the NEXT partial launch, from the previous half
+    size_t half_tiles = 0;
+    for (int l = l0; l < l_end; ++l) {
+        const int na = m->active_prefix[(size_t)std::min(m->max_nt + 1, m->max_nt - l + l0)], G = m->max_nt - l - 1;
+        const int ns = nsplit_of(l, G);
+        if (ns > 1) half_tiles = std::max(half_tiles, (size_t)na * (size_t)(G + 1) * (size_t)ns);
+    }
+    if (half_tiles)
+        if (int rc = reserve_split(m, 2 * sizeof(real2_t) * (size_t)PARTIAL_TILE * half_tiles, 0)) return rc;
+    struct Pending { int n, G, nsplit; const real2_t *buf; int l; } pend = {0, 0, 1, nullptr, -1};
+    auto flush_pending = [&]() -> int {       // a potrf-only launch (no split step follows the one that left it)
+        if (pend.n == 0) return 0;
+        hipLaunchKernelGGL(chol_partial_kernel, dim3((unsigned)pend.n), dim3(256), 0, s, m->d_desc, m->d_order, 0, 0, 1,
+                           pend.l + 1, m->max_nt, (real *)m->d_a, (real2_t *)nullptr, pend.n, pend.G, pend.nsplit, pend.buf,
+                           (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info);
+        pend.n = 0;
+        return 0;
+    };
     if (col_ev && n_ev > 0) PMK_HIP(hipStreamWaitEvent(s, col_ev[0], 0));
     hipLaunchKernelGGL(chol_first_kernel, dim3((unsigned)np), dim3(256), 0, s, m->d_desc, (real *)m->d_a, (real *)m->d_inv,
                        (const real *)m->d_y, (real *)m->d_z, m->d_info);
@@ -1370,24 +1414,20 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
         if (col_ev && l + 1 < n_ev) PMK_HIP(hipStreamWaitEvent(s, col_ev[l + 1], 0));
         if (nactive == 0) continue;
         if (int rc = ev_begin(l)) return rc;
-        // split path: K chunks so that ONE patch's tiles x chunks would fill the chip (a function of the step alone, not
-        // of the number of patches: the summation order of a tile, hence every bit of the factor, is then the same
-        // whether a patch is factorised alone or next to others -- sharded and single models stay bit-identical); a
-        // chunk is at least two block columns deep; 64-way: the serial sum in the combine costs more than it buys
-        int nsplit = 1;
-        if (m->split_mode && l >= 4) nsplit = std::max(1, std::min(std::min(16, l / 2), (want_wg + G) / (G + 1)));
+        const int nsplit = nsplit_of(l, G);
         const unsigned grid = (unsigned)(8 * ((nactive + 7) / 8) * G);
         if (nsplit > 1) {
             const int tiles = G + 1;
-            const size_t bytes = sizeof(real2_t) * (size_t)PARTIAL_TILE * (size_t)nactive * tiles * nsplit;
-            if (int rc = reserve_split(m, bytes, 0)) return rc;
-            hipLaunchKernelGGL(chol_partial_kernel, dim3((unsigned)(nactive * tiles * nsplit)), dim3(256), 0, s,
-                               m->d_desc, m->d_order, nactive, G, nsplit, l, m->max_nt, (const real *)m->d_a,
-                               (real2_t *)m->d_partial);
+            real2_t *buf = (real2_t *)m->d_partial + (size_t)(l & 1) * half_tiles * PARTIAL_TILE;     // alternate halves
+            hipLaunchKernelGGL(chol_partial_kernel, dim3((unsigned)(pend.n + nactive * tiles * nsplit)), dim3(256), 0, s,
+                               m->d_desc, m->d_order, nactive, G, nsplit, l, m->max_nt, (real *)m->d_a, buf, pend.n, pend.G,
+                               pend.nsplit, pend.buf, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info);
             hipLaunchKernelGGL((chol_step_kernel<1, 0>), dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
                                m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,
-                               (const real2_t *)m->d_partial, nsplit, m->ctx->d_clk, (const real *)m->d_x, m->th);
+                               (const real2_t *)buf, nsplit, m->ctx->d_clk, (const real *)m->d_x, m->th);
+            pend = {nactive, G, nsplit, buf, l};           // tile k + 1 of these patches: with the next launch
         } else {
+            if (int rc = flush_pending()) return rc;
 #define PMK_STEP(KD_)                                                                                                        \
             hipLaunchKernelGGL((chol_step_kernel<0, KD_>), dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,  \
                                m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,  \
@@ -1400,6 +1440,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
         }
         if (int rc = ev_end(l)) return rc;
     }
+    if (int rc = flush_pending()) return rc;
     PMK_HIP(hipGetLastError());
     if (l_end < m->max_nt - 1) return launch_cholesky_queue(m, s);
     return 0;

@@ -1351,3 +1351,34 @@ def test_dpp_kernels_and_warp_kernels_in_the_mixture_path():
             w = w / w.sum()
             yj, vj = w @ np.array([u for u, _ in uv]), w @ (np.array([v for _, v in uv]) * w)
             assert abs(Yq[j] - yj) <= 1e-7 * max(1, abs(yj)) and abs(Vq[j] - vj) <= 1e-9 + 1e-5 * vj
+
+
+@pytest.mark.timeout(1200)
+def test_single_problem_n16384_vs_lapack():
+    """SURVEY 8(f) rank 3 at scale: ONE problem of 16 384 points in 3-D (128 tile rows -- the split path by the library's
+    own choice: the potrf of each diagonal tile runs beside the next step's products) against LAPACK's Cholesky of the
+    oracle's kernel matrix, plus the weights by residual and a GP query (setupGPquery) against the formula."""
+    import scipy.linalg as sla
+    n = 16384
+    rng = np.random.Generator(np.random.PCG64(16384))
+    X = rng.uniform(0, 1, (n, 3))
+    y = np.sin(3 * X[:, 0]) + X[:, 2] ** 2
+    a, sigma2 = 6.0, 1e-4
+    th, oth = pmk.Spline34KernelType(a), O.kernel(O.SPLINE34, a)
+    m = pmk.DeviceModel([X], [y]); m.fit(th, sigma2)
+    assert np.all(m.info() == 0)
+    L, c = m.get(0, M.GET_L), m.get(0, M.GET_C)
+    U = O.kernel_matrix(oth, X)
+    U[np.diag_indices(n)] += sigma2
+    Lref = sla.cholesky(U, lower=True, check_finite=False)
+    assert np.abs(L - Lref).max() < 1e-9
+    del Lref
+    assert np.linalg.norm(U @ c - y) / (np.linalg.norm(U) * np.linalg.norm(c) + np.linalg.norm(y)) <= 1e-13
+    fq = pmk.setupGPquery(c, X, th, sigma2)
+    Xq = rng.uniform(0, 1, (8, 3))
+    mu, var = fq.many(Xq)
+    Kq = O.cross_kernel_matrix(oth, Xq, X)                       # evalkernel(Xq[j], X[i])
+    for j in range(8):
+        kq = Kq[j]
+        w = sla.solve_triangular(L, kq, lower=True, check_finite=False)
+        assert abs(mu[j] - kq @ c) <= 1e-9 * max(1, abs(kq @ c)) and abs(var[j] - (1.0 - w @ w)) <= 1e-9

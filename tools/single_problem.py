@@ -12,7 +12,8 @@ import patchmixturekriging_amd as pmk  # noqa: E402
 
 
 def main():
-    ns = [int(a) for a in sys.argv[1:]] or [8192, 16384, 32768]
+    ns = [int(a) for a in sys.argv[1:] if a.isdigit()] or [8192, 16384, 32768]
+    results = []
     ctx = pmk.default_context()
     th = pmk.Spline34KernelType(6.0)
     for n in ns:
@@ -39,8 +40,17 @@ def main():
             line += "\n      stages ms %s; step launches ms: first %s ... mid %s ... last %s\n     " % (
                 st, [round(v, 2) for v in steps[:3]], [round(v, 2) for v in steps[nt // 2 - 1:nt // 2 + 2]], [round(v, 2) for v in steps[-3:]])
             line += "  %s %.1f ms = %.1f TFLOP/s" % ("split" if split else "batched", dt * 1e3, n ** 3 / 3 / dt / 1e12)
+            results.append({"n": n, "path": "split" if split else "batched", "fit_ms": dt * 1e3, "stage_ms": st,
+                            "alg_flops": n ** 3 / 3.0 + 2.0 * n ** 2,
+                            "roofline": {"bound": "mfma", "achieved": (n ** 3 / 3.0 + 2.0 * n ** 2) / dt / 1e12, "peak": 78.6,
+                                         "unit": "TFLOP/s", "frac": (n ** 3 / 3.0 + 2.0 * n ** 2) / dt / 1e12 / 78.6}})
             del m
         print(line)
+    out = os.environ.get("SP_JSON")
+    if out:
+        import json
+        json.dump({"what": "single problem (P = 1), 3-D Spline34(6), sigma2 = 1e-4, fp64: whole fit (kernel matrix + factor + solves), "
+                           "wall clock, mean of 3", "results": results}, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":
