@@ -474,7 +474,7 @@ void pmk_model_destroy(pmk_model *m)
     dev_free(m->d_order);
     dev_free(m->d_sched);
     dev_free(m->d_sched_init);
-    for (void **p : {&m->d_qtasks, &m->d_diag, &m->d_x, &m->d_y, &m->d_z, &m->d_c, &m->d_a, &m->d_inv, &m->d_strip, &m->d_partial, &m->d_solve_part}) {
+    for (void **p : {&m->d_qtasks, &m->d_diag, &m->d_x, &m->d_y, &m->d_z, &m->d_c, &m->d_a, &m->d_inv, &m->d_strip, &m->d_partial, &m->d_solve_part, &m->d_chain}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -714,7 +714,16 @@ int pmk_model_info(pmk_model *m, int32_t *info)
     std::vector<int32_t> sched((size_t)SCHED_HEADS + 8 * 16, 0);
     if (m->queue_used)
         PMK_HIP(hipMemcpyAsync(sched.data(), m->d_sched, sizeof(int32_t) * sched.size(), hipMemcpyDeviceToHost, m->ctx->stream));
+    int32_t chain_err = 0;
+    if (m->chain_used)
+        PMK_HIP(hipMemcpyAsync(&chain_err, m->d_chain, sizeof(int32_t), hipMemcpyDeviceToHost, m->ctx->stream));
     PMK_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (chain_err != 0) {
+        // solve_back_chain_kernel: a block waited 3 s for the block above it (never seen; bounded so that a fault ends)
+        PMK_HIP(hipMemsetAsync(m->d_chain, 0, sizeof(int32_t), m->ctx->stream));
+        set_error("pmk_model_fit: the chained back substitution timed out waiting for block %d", (int)chain_err - 1);
+        return -4;
+    }
     if (m->queue_used) {
         // the task-queue factorisation: no time-out, and every XCD's list drained
         bool drained = sched[0] == 0;

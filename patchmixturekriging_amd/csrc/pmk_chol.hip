@@ -22,6 +22,7 @@
 // The slab is read once per block column (left-looking): reads only, no trailing-matrix
 // read-modify-write.  chol_backsolve_kernel then gives c = L^-T z.
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <numeric>
 
@@ -1002,6 +1003,57 @@ __global__ __launch_bounds__(256) void solve_partial_kernel(const PatchDesc *__r
     }
 }
 
+// z_s = -Ninv_s (v_s - sum_{jb<s} L[s][jb] z_jb), s = 0..3: the forward substitution of one diagonal tile (operands as in
+// diag_solve_back)
+__device__ __forceinline__ void diag_solve_fwd(const real *tri, real *v, real *w, int tid)
+{
+    const int sb = tid >> 5, i = tid & 31;
+    for (int s2 = 0; s2 < 4; ++s2) {
+        if (tid < TILE && sb == s2) {
+            real t = v[32 * s2 + i];
+            for (int jb = 0; jb < s2; ++jb) {
+                const real *blk = tri + 1024 * (s2 * (s2 - 1) / 2 + jb);
+                for (int c = 0; c < SB; ++c) t -= blk[i + 32 * c] * w[32 * jb + c];
+            }
+            v[32 * s2 + i] = t;
+        }
+        __syncthreads();
+        if (tid < TILE && sb == s2) {
+            const real *nb = tri + 1024 * (6 + s2);
+            real t = 0;
+            for (int c = 0; c <= i; ++c) t -= nb[i + 32 * c] * v[32 * s2 + c];      // -Ninv = L_ss^-1 (lower)
+            w[32 * s2 + i] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// c_s = -Ninv_s^T (v_s - sum_{jb>s} L[jb][s]^T c_jb), s = 3..0: the backward substitution of one 128 x 128 diagonal tile
+// whose operands stage_tri_operands left in `tri`; right-hand side in v, solution in w (LDS).  Entered by every thread of
+// the workgroup (threads 0..127 work).
+__device__ __forceinline__ void diag_solve_back(const real *tri, real *v, real *w, int tid)
+{
+    const int sb = tid >> 5, i = tid & 31;
+    for (int s2 = 3; s2 >= 0; --s2) {
+        if (tid < TILE && sb == s2) {
+            real t = v[32 * s2 + i];
+            for (int jb = s2 + 1; jb < 4; ++jb) {
+                const real *blk = tri + 1024 * (jb * (jb - 1) / 2 + s2) + 32 * i;     // column i of block (jb, s2)
+                for (int r = 0; r < SB; ++r) t -= blk[r] * w[32 * jb + r];
+            }
+            v[32 * s2 + i] = t;
+        }
+        __syncthreads();
+        if (tid < TILE && sb == s2) {
+            const real *nb = tri + 1024 * (6 + s2) + 32 * i;                           // column i of Ninv_s
+            real t = 0;
+            for (int r = i; r < SB; ++r) t -= nb[r] * v[32 * s2 + r];
+            w[32 * s2 + i] = t;
+        }
+        __syncthreads();
+    }
+}
+
 template <int DIR>
 __global__ __launch_bounds__(256) void solve_block_kernel(const PatchDesc *__restrict__ descs, int j, int nchunk,
                                                           const real *__restrict__ A, const real *__restrict__ ninv,
@@ -1027,47 +1079,127 @@ __global__ __launch_bounds__(256) void solve_block_kernel(const PatchDesc *__res
     __syncthreads();
     const int sb = tid >> 5, i = tid & 31;          // threads 0..127: block sb, entry i
     if (DIR > 0) {
-        // z_s = -Ninv_s (v_s - sum_{jb<s} L[s][jb] z_jb)
-        for (int s2 = 0; s2 < 4; ++s2) {
-            if (tid < TILE && sb == s2) {
-                real t = v[32 * s2 + i];
-                for (int jb = 0; jb < s2; ++jb) {
-                    const real *blk = tri + 1024 * (s2 * (s2 - 1) / 2 + jb);
-                    for (int c = 0; c < SB; ++c) t -= blk[i + 32 * c] * w[32 * jb + c];
-                }
-                v[32 * s2 + i] = t;
-            }
-            __syncthreads();
-            if (tid < TILE && sb == s2) {
-                const real *nb = tri + 1024 * (6 + s2);
-                real t = 0;
-                for (int c = 0; c <= i; ++c) t -= nb[i + 32 * c] * v[32 * s2 + c];      // -Ninv = L_ss^-1 (lower)
-                w[32 * s2 + i] = t;
-            }
-            __syncthreads();
-        }
+        diag_solve_fwd(tri, v, w, tid);
     } else {
-        // c_s = -Ninv_s^T (v_s - sum_{jb>s} L[jb][s]^T c_jb)
-        for (int s2 = 3; s2 >= 0; --s2) {
-            if (tid < TILE && sb == s2) {
-                real t = v[32 * s2 + i];
-                for (int jb = s2 + 1; jb < 4; ++jb) {
-                    const real *blk = tri + 1024 * (jb * (jb - 1) / 2 + s2) + 32 * i;     // column i of block (jb, s2)
-                    for (int r = 0; r < SB; ++r) t -= blk[r] * w[32 * jb + r];
-                }
-                v[32 * s2 + i] = t;
-            }
-            __syncthreads();
-            if (tid < TILE && sb == s2) {
-                const real *nb = tri + 1024 * (6 + s2) + 32 * i;                           // column i of Ninv_s
-                real t = 0;
-                for (int r = i; r < SB; ++r) t -= nb[r] * v[32 * s2 + r];
-                w[32 * s2 + i] = t;
-            }
-            __syncthreads();
-        }
+        diag_solve_back(tri, v, w, tid);
     }
     if (tid < TILE) sol[pd.yoff + d0 + tid] = w[tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The triangular solves of the split path as ONE launch each (few, long patches: the block-by-block launches above cost
+// two launch latencies per block).  DIR = +1: z = L^-1 y, workgroup b of a patch owns block k = b and needs the blocks
+// above it; DIR = -1: c = L^-T z, workgroup b owns block k = nt - 1 - b and needs the blocks below it.  Either way a
+// workgroup waits only for workgroups with LOWER ids, which were dispatched earlier: progress by construction, whatever
+// fits on the chip.  It folds the tiles of its block row (forward) / block column (backward) into its right-hand side
+// in a fixed order as the solution blocks appear -- one flag word per block holding the launch's epoch (no clearing
+// between fits) -- then solves its diagonal tile and publishes its block: write-through stores, drained, barrier, flag
+// (put1).  A wave owns 16 columns of every tile and reads them in 1 KiB row segments; every wave polls for itself, the
+// next tile is in flight while it waits, partial sums stay in the lanes until the end.  Solution blocks are read with
+// sc1 loads behind the matched poll (nobody reads a block before its flag: no stale line can exist).  Spins are
+// bounded; a time-out raises the error word.  The summation order of a block is a function of the block alone.
+// ---------------------------------------------------------------------------------------------
+constexpr int CHAIN_THREADS = 512;
+template <int DIR>
+__global__ __launch_bounds__(CHAIN_THREADS) void solve_chain_kernel(const PatchDesc *__restrict__ descs,
+                                                                    const real *__restrict__ A, const real *__restrict__ ninv,
+                                                                    const real *__restrict__ rhs, real *sol, int32_t *flags,
+                                                                    int32_t *err, int epoch, int max_nt)
+{
+    const PatchDesc pd = descs[blockIdx.y];
+    if ((int)blockIdx.x >= pd.nt) return;
+    const int k = DIR > 0 ? (int)blockIdx.x : pd.nt - 1 - (int)blockIdx.x;
+    int32_t *fl = flags + (int64_t)blockIdx.y * max_nt;
+    __shared__ real tri[TRI_LDS_DOUBLES];
+    __shared__ real v[TILE], w[TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const real *S = A + pd.aoff;
+    const int64_t ld = pd.ld, d0 = (int64_t)k * TILE;
+    constexpr int NW = CHAIN_THREADS / 64, NC = TILE / NW;            // waves, columns of a tile per wave
+    stage_tri_operands(tri, S + d0 + d0 * ld, ld, ninv + pd.ioff + (int64_t)k * (4 * SB * SB), tid, CHAIN_THREADS);
+    // tile t of this block's sweep: forward (k, t), columns 128 t + ..., rows d0 + ...; backward (t, k), columns d0 + ...,
+    // rows 128 t + ...; a lane holds rows 2 lane, 2 lane + 1 of the wave's NC columns
+    const real *base = DIR > 0 ? S + (int64_t)(NC * wave) * ld + d0 + 2 * lane : S + (d0 + NC * wave) * ld + 2 * lane;
+    const int64_t tstep = DIR > 0 ? (int64_t)TILE * ld : (int64_t)TILE;
+    real *ss = sol + pd.yoff;
+    const int t_first = DIR > 0 ? 0 : pd.nt - 1, t_end = k, dt = DIR > 0 ? 1 : -1;     // t = t_first, t_first + dt, ... != k
+    real2_t sum[NC], nxt[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) sum[j] = real2_t{0, 0};
+    if (t_first != t_end) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+            nxt[j] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(base + j * ld + t_first * tstep));
+    }
+    for (int t = t_first; t != t_end; t += dt) {
+        real2_t cur[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) cur[j] = nxt[j];
+        if (t + dt != t_end) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j)
+                nxt[j] = __builtin_nontemporal_load(reinterpret_cast<const real2_t *>(base + j * ld + (t + dt) * tstep));
+        }
+        // block t of the solution is there?  (every wave for itself: no barrier in this loop)
+        if (__hip_atomic_load(fl + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                __builtin_amdgcn_s_sleep(4);
+                if (__hip_atomic_load(fl + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) break;
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > QUEUE_SPIN_TICKS) {
+                    if (lane == 0) __hip_atomic_store(err, 1 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (DIR > 0) {
+            // the wave's NC entries of z_t, one per lane (lanes 0..NC-1), broadcast column by column
+            const real zl = __hip_atomic_load(ss + (int64_t)t * TILE + NC * wave + (lane & (NC - 1)), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const real zj = __shfl(zl, j);
+                sum[j & 3] += cur[j] * real2_t{zj, zj};
+            }
+        } else {
+            real2_t ci;
+            ci[0] = __hip_atomic_load(ss + (int64_t)t * TILE + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ci[1] = __hip_atomic_load(ss + (int64_t)t * TILE + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) sum[j] += cur[j] * ci;
+        }
+    }
+    if (DIR > 0) {
+        // rows live in the lanes: the waves' partial sums meet in LDS (tri is not touched before the barrier below... it is
+        // being staged: use a separate array)
+        __shared__ real red[NW * TILE];
+        const real2_t r = (sum[0] + sum[1]) + (sum[2] + sum[3]);
+        *reinterpret_cast<real2_t *>(red + wave * TILE + 2 * lane) = r;
+        __syncthreads();
+        if (tid < TILE) {
+            real acc = rhs[pd.yoff + d0 + tid];
+#pragma unroll
+            for (int u = 0; u < NW; ++u) acc -= red[u * TILE + tid];
+            v[tid] = acc;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            real r = sum[j][0] + sum[j][1];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+            if (lane == 0) v[NC * wave + j] = rhs[pd.yoff + d0 + NC * wave + j] - r;
+        }
+    }
+    __syncthreads();
+    if (DIR > 0) diag_solve_fwd(tri, v, w, tid);
+    else diag_solve_back(tri, v, w, tid);
+    if (tid < TILE) put1<true>(ss + d0 + tid, w[tid]);
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(fl + k, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1451,6 +1583,34 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
 static int launch_split_solves(pmk_model *m, hipStream_t s)
 {
     const int P = (int)m->P;
+    // one chained launch per solve when the patches' blocks (nearly) fit on the chip together, else block by block
+    static const char *chain_env = std::getenv("PMK_SPLIT_CHAIN");
+    const bool chain = chain_env ? std::atoi(chain_env) != 0 : (int64_t)P * m->max_nt <= 2 * (int64_t)m->ctx->num_cu;
+    m->chain_used = chain;
+    if (chain) {
+        const size_t words = 16 + 2 * (size_t)P * (size_t)m->max_nt;          // error word, flags of z, flags of c
+        if (words > m->chain_words) {
+            if (m->d_chain) PMK_HIP(hipFree(m->d_chain));
+            m->d_chain = nullptr; m->chain_words = 0;
+            PMK_HIP(hipMalloc(&m->d_chain, sizeof(int32_t) * words));
+            m->chain_words = words;
+            m->chain_epoch = INT32_MAX;
+        }
+        if (m->chain_epoch == INT32_MAX) {
+            PMK_HIP(hipMemsetAsync(m->d_chain, 0, sizeof(int32_t) * m->chain_words, s));
+            m->chain_epoch = 0;
+        }
+        ++m->chain_epoch;
+        int32_t *w = (int32_t *)m->d_chain;
+        const dim3 grid((unsigned)m->max_nt, (unsigned)P);
+        hipLaunchKernelGGL(solve_chain_kernel<1>, grid, dim3(CHAIN_THREADS), 0, s, m->d_desc, (const real *)m->d_a,
+                           (const real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, w + 16, w, m->chain_epoch, m->max_nt);
+        hipLaunchKernelGGL(solve_chain_kernel<-1>, grid, dim3(CHAIN_THREADS), 0, s, m->d_desc, (const real *)m->d_a,
+                           (const real *)m->d_inv, (const real *)m->d_z, (real *)m->d_c, w + 16 + (size_t)P * (size_t)m->max_nt, w,
+                           m->chain_epoch, m->max_nt);
+        PMK_HIP(hipGetLastError());
+        return 0;
+    }
     const int max_chunks = 128;      // a function of the block alone, not of P: bit-identical results however patches are grouped
     if (int rc = reserve_split(m, 0, sizeof(real) * (size_t)P * max_chunks * TILE)) return rc;
     real *part = (real *)m->d_solve_part;

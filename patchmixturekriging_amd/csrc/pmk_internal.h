@@ -120,6 +120,8 @@ struct pmk_model {
     int qfstride = 0;
     void *d_partial = nullptr; size_t partial_bytes = 0;      // partial product tiles of one step
     void *d_solve_part = nullptr; size_t solve_bytes = 0;     // partial matrix-vector products of one solve block
+    void *d_chain = nullptr; size_t chain_words = 0;          // solve_back_chain_kernel: error word, then one flag word per block
+    int chain_epoch = 0; bool chain_used = false;             // the flags hold the epoch of the launch that set them
     int64_t tot_a = 0, tot_x = 0, tot_y = 0, tot_inv = 0;
     bool fitted = false;
     pmk_kernel_desc th{};

@@ -20,6 +20,7 @@
 // row -- timing only, no data is handed over, so a missed rendezvous costs time, never correctness)
 // and the block row of L is then served to all of them by ONE fetch into that XCD's L2.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <tuple>
 
@@ -422,6 +423,13 @@ int build_strip_tasks(pmk_query *q, hipStream_t s)
     q->nsync = 0;
     if (tasks.empty()) return 0;
     const int64_t slots = std::min<int64_t>(q->ntasks, (int64_t)m->ctx->num_cu);     // one 8-wave workgroup per CU
+    if (std::getenv("PMK_PRED_DEBUG")) {
+        int64_t cols = 0;
+        for (const StripTask &t : tasks) cols += t.count;
+        std::fprintf(stderr, "strips %lld (%.2f rounds of %lld), %lld items = %.1f %% of their columns, last round %lld strips\n",
+                     (long long)q->ntasks, (double)q->ntasks / (double)slots, (long long)slots, (long long)cols,
+                     100.0 * (double)cols / ((double)q->ntasks * TQ), (long long)(q->ntasks - (q->ntasks - 1) / slots * slots));
+    }
     // lock-step groups: consecutive tasks of one round that land on one XCD and stream the same factor
     {
         int64_t g0 = 0;
