@@ -423,7 +423,7 @@ __device__ __forceinline__ void lookahead_update(const PatchDesc &pd, real *__re
                     acc.f[fi][0][q] += v[0];
                     acc.f[fi][1][q] += v[1];
                 }
-        gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + t0 + c0 * ld, ld, S + t0 + 32 * wave + c0 * ld, ld, TILE, lane);
+        if (ce > cb) gemm_nt<4, 1, PF_CHOL, PFJ_CHOL>(acc, S + t0 + c0 * ld, ld, S + t0 + 32 * wave + c0 * ld, ld, TILE, lane);
 #pragma unroll
         for (int fi = 0; fi < 8; ++fi)
 #pragma unroll
@@ -433,7 +433,7 @@ __device__ __forceinline__ void lookahead_update(const PatchDesc &pd, real *__re
                 o[1] = -acc.f[fi][1][q];
                 *reinterpret_cast<real2_t *>(outl + tile_i(fi, lane, q) * ld) = o;
             }
-        if (tid < TILE) lds[POTRF_RHS + tid] = (real)0;       // z comes from the solve sweeps of the split path
+        if (tid < TILE && ce > cb) lds[POTRF_RHS + tid] = (real)0;       // z comes from the solve sweeps of the split path
     } else if (!(h == 0 && g == 1)) {
         // lower 64 x 64 sub-tiles: acc = -A up-front (all the sub-tile's loads in flight at once), the GEMM adds
         // L L^T, the store negates
@@ -537,7 +537,8 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
                                                            real *__restrict__ z, int32_t *__restrict__ info,
                                                            const real2_t *__restrict__ partial, int nsplit,
                                                            unsigned long long *__restrict__ clk,
-                                                           const real *__restrict__ x, pmk_kernel_desc th)
+                                                           const real *__restrict__ x, pmk_kernel_desc th,
+                                                           int nsplit_look)
 {
     __shared__ real lds[TRI_LDS_DOUBLES];
     int slot, bx;
@@ -549,7 +550,20 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(const PatchDesc *__re
         // few patches: their block rows are dealt over ALL XCDs (one XCD per patch would leave most of the chip idle);
         // critical workgroups first
         const int lid = blockIdx.x;
-        if (lid >= nactive * G) return;
+        if (lid >= nactive * (G + 1)) return;
+        if (lid >= nactive * G) {
+            if (nsplit_look == 0) return;                                // PMK_SPLIT_PREREDUCE=0: the factorising workgroup does it
+            // one more workgroup per patch: the partial tiles of the NEXT diagonal tile (block columns 0..k-1) are folded
+            // into the slab here, beside the block rows, instead of by the workgroup that factorises it (whose chain of
+            // partial sums + block column k + potrf is what a split step waits for).  Same sums in the same order.
+            slot = lid - nactive * G;
+            const int pid = order[slot];
+            const PatchDesc pd = descs[pid];
+            const int k = launch - (max_nt - pd.nt);
+            lookahead_update<1, false>(pd, A + pd.aoff, nullptr, nullptr, k, lds,
+                                       partial + (((int64_t)slot * (G + 1) + G) * nsplit) * PARTIAL_TILE, nsplit_look, 0, 0);
+            return;
+        }
         if (lid < nactive) { slot = lid; bx = 0; }
         else { const int j = lid - nactive; slot = j / (G - 1); bx = 1 + j % (G - 1); }
     } else {
@@ -1526,6 +1540,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
     }
     if (half_tiles)
         if (int rc = reserve_split(m, 2 * sizeof(real2_t) * (size_t)PARTIAL_TILE * half_tiles, 0)) return rc;
+    static const bool prereduce = !std::getenv("PMK_SPLIT_PREREDUCE") || std::atoi(std::getenv("PMK_SPLIT_PREREDUCE")) != 0;
     struct Pending { int n, G, nsplit; const real2_t *buf; int l; } pend = {0, 0, 1, nullptr, -1};
     auto flush_pending = [&]() -> int {       // a potrf-only launch (no split step follows the one that left it)
         if (pend.n == 0) return 0;
@@ -1554,16 +1569,22 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
             hipLaunchKernelGGL(chol_partial_kernel, dim3((unsigned)(pend.n + nactive * tiles * nsplit)), dim3(256), 0, s,
                                m->d_desc, m->d_order, nactive, G, nsplit, l, m->max_nt, (real *)m->d_a, buf, pend.n, pend.G,
                                pend.nsplit, pend.buf, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info);
-            hipLaunchKernelGGL((chol_step_kernel<1, 0>), dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
+            // Fold the next diagonal tile's partial sums into the slab beside this step's block rows (one more workgroup per
+            // patch)?  Only where the workgroup that factorises it is what the NEXT partial launch waits for: its products
+            // are short (<= 4 block columns per chunk).  Measured: n = 8192 15.5 -> 14.0 ms; at 16384 and beyond the
+            // products are the longer leg and the extra workgroup only stretches this launch (40.0 -> 43.7 ms if always on).
+            const bool fold = prereduce && G >= 2 && (l + 1) <= 4 * nsplit_of(l + 1, G - 1);
+            hipLaunchKernelGGL((chol_step_kernel<1, 0>), dim3(grid + (fold ? (unsigned)nactive : 0u)), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,
                                m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,
-                               (const real2_t *)buf, nsplit, m->ctx->d_clk, (const real *)m->d_x, m->th);
-            pend = {nactive, G, nsplit, buf, l};           // tile k + 1 of these patches: with the next launch
+                               (const real2_t *)buf, nsplit, m->ctx->d_clk, (const real *)m->d_x, m->th, fold ? nsplit : 0);
+            pend = {nactive, G, fold ? 0 : nsplit, buf, l};                // tile k + 1 of these patches: with the next launch (its partial
+                                                           // tiles are folded in by the step launch above: none left)
         } else {
             if (int rc = flush_pending()) return rc;
 #define PMK_STEP(KD_)                                                                                                        \
             hipLaunchKernelGGL((chol_step_kernel<0, KD_>), dim3(grid), dim3(256), 0, s, m->d_desc, m->d_order, nactive, G, l,  \
                                m->max_nt, (real *)m->d_a, (real *)m->d_inv, (const real *)m->d_y, (real *)m->d_z, m->d_info,  \
-                               (const real2_t *)nullptr, 1, m->ctx->d_clk, (const real *)m->d_x, m->th)
+                               (const real2_t *)nullptr, 1, m->ctx->d_clk, (const real *)m->d_x, m->th, 0)
             // fused kernel-matrix build (pmk_model_fit decides): the strictly lower tiles are evaluated at their first use
             if (m->fuse_k1 && m->D == 2) PMK_STEP(2);
             else if (m->fuse_k1 && m->D == 3) PMK_STEP(3);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """one large GP problem (P = 1): fit time by factorisation path (batched one-workgroup-per-block-row vs split-K)
-    python tools/single_problem.py [n ...]"""
+    python tools/single_problem.py [n ...]        (SP_PATHS=split: the split path only; SP_JSON=file: results as JSON)"""
 import os
 import sys
 import time
@@ -21,7 +21,7 @@ def main():
         X = rng.uniform(0, 1, (n, 3))
         y = np.sin(3 * X[:, 0]) + X[:, 2] ** 2
         line = "n = %6d (%.1f GFLOP n^3/3):" % (n, n ** 3 / 3 / 1e9)
-        for split in (0, 1):
+        for split in ((1,) if os.environ.get("SP_PATHS") == "split" else (0, 1)):
             m = pmk.DeviceModel([X], [y])
             ctx.L.pmk_test_model_set_split(m.h, split)
             m.fit(th, 1e-4); ctx.synchronize()
