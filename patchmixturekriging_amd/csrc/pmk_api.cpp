@@ -968,6 +968,7 @@ void pmk_query_destroy(pmk_query *q)
 {
     if (!q) return;
     dev_free(q->d_xq); dev_free(q->d_qdiag); dev_free(q->d_home); dev_free(q->d_cnt); dev_free(q->d_qoff);
+    dev_free(q->d_stage_r); dev_free(q->d_stage_t);
     dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
     dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_roff);
     dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w); dev_free(q->d_yq); dev_free(q->d_vq); dev_free(q->d_flag);
@@ -989,12 +990,15 @@ int query_reserve(pmk_query *q, int64_t Nq)
     if (Nq <= q->nq_cap) return 0;
     const bool regrow = q->nq_cap > 0;
     dev_free(q->d_xq); dev_free(q->d_home); dev_free(q->d_cnt); dev_free(q->d_qoff); dev_free(q->d_yq); dev_free(q->d_vq);
+    dev_free(q->d_stage_r); dev_free(q->d_stage_t);
     q->nq_cap = 0;
     const int64_t cap = Nq + (regrow ? Nq / 8 : 0);
     int rc = 0;
     rc |= dev_alloc(&q->d_xq, cap * m->D);
     rc |= dev_alloc(&q->d_home, cap);
     rc |= dev_alloc(&q->d_cnt, cap + 1);
+    rc |= dev_alloc(&q->d_stage_r, 4 * cap);          // PLAN_STAGE rows (pmk_kernels.hip)
+    rc |= dev_alloc(&q->d_stage_t, 4 * cap);
     rc |= dev_alloc(&q->d_qoff, cap + 1);
     rc |= dev_alloc(&q->d_yq, cap);
     rc |= dev_alloc(&q->d_vq, cap);

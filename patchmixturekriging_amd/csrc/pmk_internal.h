@@ -146,6 +146,8 @@ struct pmk_query {
     double *d_qdiag = nullptr;      // per-query addend of k(xq, xq) (pmk_query_set_diag), or null
     int32_t *d_home = nullptr;      // Nq
     int32_t *d_cnt = nullptr;       // Nq : items per query (neighbours + 1)
+    int32_t *d_stage_r = nullptr;   // PLAN_STAGE x nq_cap : first neighbour hits of the count pass (region), see plan_kernel
+    double *d_stage_t = nullptr;    //                        ... and their t
     int64_t *d_qoff = nullptr;      // Nq+1
     int64_t total = 0;
     int64_t item_cap = 0;           // capacity of the per-item buffers (reused across plans)
