@@ -242,10 +242,17 @@ __device__ unsigned long long g_trace[TRACE_WORDS * TRACE_MAX_WG];
 // first diagonal tile of every patch: nothing to apply, rhs = y_0
 __global__ __launch_bounds__(256, 2) void chol_first_kernel(const PatchDesc *__restrict__ descs, real *__restrict__ A,
                                                             real *__restrict__ ninv, const real *__restrict__ y,
-                                                            real *__restrict__ z, int32_t *__restrict__ info)
+                                                            real *__restrict__ z, int32_t *__restrict__ info,
+                                                            unsigned long long *__restrict__ clk)
 {
     __shared__ real lds[POTRF_END];
     const PatchDesc pd = descs[blockIdx.x];
+    // the first launch of a factorisation also clears what the later ones accumulate into (nine small memsets otherwise):
+    // the patch's status word and the step launches' shader-clock stamps (the strip kernel's pair, words 128-129 of each
+    // XCD's block, stays)
+    if (threadIdx.x == 0) info[blockIdx.x] = 0;
+    if (clk && blockIdx.x == 0)
+        for (int e = threadIdx.x; e < 8 * 128; e += 256) clk[130 * (e >> 7) + (e & 127)] = 0;
     if (threadIdx.x < TILE) lds[POTRF_RHS + threadIdx.x] = y[pd.yoff + threadIdx.x];
     __syncthreads();
     tile_potrf(A + pd.aoff, pd.ld, lds, ninv + pd.ioff, z + pd.yoff, info + blockIdx.x, 0);
@@ -1489,9 +1496,6 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
     static_assert(TILE % (4 * PF_DIAG) == 0 && TILE % (4 * PF_CHOL) == 0 && TILE % (4 * PFJ_CHOL) == 0,
                   "prefetch depth must divide TILE/4");
     if (p0 != 0 || np != m->P) { set_error("launch_cholesky: sub-batches are not supported"); return -2; }
-    PMK_HIP(hipMemsetAsync(m->d_info, 0, sizeof(int32_t) * (size_t)np, s));
-    for (int x = 0; x < 8; ++x)         // shader-clock probe of the step launches (the strip kernel's pair stays)
-        PMK_HIP(hipMemsetAsync(m->ctx->d_clk + 130 * x, 0, sizeof(unsigned long long) * 128, s));
     pmk_ctx *c = m->ctx;
     c->panel_n = 0;
     m->queue_used = false;
@@ -1501,7 +1505,13 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
         if (!m->queue_built)
             if (int rc = build_queue(m)) return rc;
         l_end = m->queue_l0;
-        if (l_end == 0) return launch_cholesky_queue(m, s);
+        if (l_end == 0) {
+            // no chol_first_kernel in front: clear the status words and the clock stamps here
+            PMK_HIP(hipMemsetAsync(m->d_info, 0, sizeof(int32_t) * (size_t)np, s));
+            for (int x = 0; x < 8; ++x)
+                PMK_HIP(hipMemsetAsync(m->ctx->d_clk + 130 * x, 0, sizeof(unsigned long long) * 128, s));
+            return launch_cholesky_queue(m, s);
+        }
     }
     const bool fine = c->timers >= 2;
     const int want_wg = 2 * c->num_cu;                     // workgroups that fill the chip (two per CU)
@@ -1552,7 +1562,7 @@ int launch_cholesky(pmk_model *m, hipStream_t s, int64_t p0, int64_t np, const h
     };
     if (col_ev && n_ev > 0) PMK_HIP(hipStreamWaitEvent(s, col_ev[0], 0));
     hipLaunchKernelGGL(chol_first_kernel, dim3((unsigned)np), dim3(256), 0, s, m->d_desc, (real *)m->d_a, (real *)m->d_inv,
-                       (const real *)m->d_y, (real *)m->d_z, m->d_info);
+                       (const real *)m->d_y, (real *)m->d_z, m->d_info, m->ctx->d_clk);
     for (int l = l0; l < l_end; ++l) {
         // patch p runs block column k = l - (max_nt - nt_p) at launch l (end-aligned); it takes part from k = l0 on:
         // nt_p >= max_nt - l + l0.  Those patches are a prefix of `order` (sorted by nt, largest first).

@@ -1184,7 +1184,7 @@ def test_plan_kernel_in_both_dot_modes_vs_oracle(D, dot_mode):
     th = pmk.Spline34KernelType(2.0)
     m = pmk.DeviceModel(X_parts, [y[i] for i in X_parts_inds]); m.fit(th, 1e-3); m.set_bsp(root, 0)
     Xq = rng.uniform(-1, 1, (3000, D))
-    radius, delta = (0.05, 1e-7) if D == 3 else (0.3, 1e-6)
+    radius, delta = (0.05, 1e-7) if D == 3 else (0.6, 1e-6)
     q = pmk.DeviceQuery(m, Xq); q.plan(radius, delta)
     dbg = q.debug()
     for j in range(0, 3000, 3 if D == 3 else 1):
@@ -1195,6 +1195,13 @@ def test_plan_kernel_in_both_dot_modes_vs_oracle(D, dot_mode):
         assert np.array_equal(dbg["item_t"][s][:-1], ts[keep])
     host_home = [pmk.findpartition(x, root) for x in Xq[:500]]
     assert np.array_equal(host_home, dbg["home"][:500])
+    # both forms of the fill pass ran: a workgroup (256 queries) copies the hits its count pass staged when none of its
+    # queries has more than four, and walks the hyperplanes again otherwise
+    hits = np.diff(dbg["item_offsets"]) - 1
+    blocks = [hits[b:b + 256] for b in range(0, 3000, 256)]
+    assert any(b.max() <= 4 and b.max() >= 1 for b in blocks)
+    if D == 2:
+        assert any(b.max() > 4 for b in blocks)       # radius 0.6: three of the twelve workgroups
 
 
 def test_task_queue_factorisation_is_bit_identical_to_the_step_launches(monkeypatch):
