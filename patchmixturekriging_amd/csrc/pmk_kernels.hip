@@ -150,58 +150,142 @@ __global__ __launch_bounds__(256) void plan_kernel(int64_t Nq, const double *__r
             return;
         }
     }
+    int tree_doubles = 0;
     if (LDS) {
         const int nn = (int)(P - 1);
         double *sv = plan_sm, *sc = plan_sm + (size_t)nn * D;
         int32_t *sp = reinterpret_cast<int32_t *>(sc + nn);
         for (int e = threadIdx.x; e < nn * D; e += 256) sv[e] = hv_g[e];
         for (int e = threadIdx.x; e < nn; e += 256) { sc[e] = hc_g[e]; sp[e] = pre_g[e]; }
-        __syncthreads();
         hv = sv; hc = sc; pre = sp;
+        tree_doubles = nn * (D + 1) + (nn + 1) / 2;
     }
+    // Per-wave scratch behind the tree.  A query is within `radius` of a given (infinite) hyperplane with a few per cent
+    // probability, whatever the level of the plane -- so with 64 unrelated queries in a wave nearly EVERY hyperplane has a
+    // candidate in some lane, and the two leaf searches behind the distance test (2 x levels dependent loads) ran for the
+    // whole wave almost every time: 25 x the work.  Candidates (lane, plane) are therefore queued per wave and evaluated 64
+    // at a time, one per lane, on the source lane's point (same operations in the same order: same bits); an accepted
+    // candidate sets a bit in the source lane's mask, and each lane then walks its own few bits in pre-order to emit its
+    // items exactly as the direct loop did.  Planes are taken in chunks of 256 (8 mask words per lane).
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int WAVE_DOUBLES = 64 * D + 32 + 256 + 64;      // points, homes (int32), masks (8 x uint32), queue (128 x uint32)
+    double *wsm = plan_sm + tree_doubles + wave * WAVE_DOUBLES;
+    double *qp = wsm;
+    int32_t *qhome = reinterpret_cast<int32_t *>(wsm + 64 * D);
+    uint32_t *bits = reinterpret_cast<uint32_t *>(wsm + 64 * D + 32);
+    uint32_t *queue = reinterpret_cast<uint32_t *>(wsm + 64 * D + 32 + 256);
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= Nq) return;
+    const bool valid = j < Nq;
     double p[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) p[d] = xq[j * D + d];
+    for (int d = 0; d < D; ++d) p[d] = valid ? xq[j * D + d] : 0.0;
+    __syncthreads();                                          // the tree is staged
     const int home = find_leaf<D>(hv, hc, levels, P, p, dot_mode);
+#pragma unroll
+    for (int d = 0; d < D; ++d) qp[lane * D + d] = p[d];
+    qhome[lane] = home;
     int count = 0;
     int64_t base = 0;
-    if (FILL) base = qoff[j];
-    for (int i = 0; i < (int)(P - 1); ++i) {
-        const int h = pre[i];
-        double u[D];
+    if (FILL && valid) base = qoff[j];
+    double r2lo = -1.0, r2hi = __builtin_inf();                     // radius^2 not representable well: always take the root
+    if (radius > 1e-140 && radius < 1e150) {
+        // sqrt(s) < radius decided without the root wherever s is clear of radius^2 (sqrt is correctly rounded and
+        // monotone); the root itself is taken only inside the band: same decisions
+        const double r2 = radius * radius;
+        r2lo = r2 * (1.0 - 0x1p-50);
+        r2hi = r2 * (1.0 + 0x1p-50);
+    } else if (!(radius > 0.0)) {
+        r2hi = -1.0;                                                 // radius <= 0 or NaN: sqrt(s) < radius never holds
+    }
+    auto wave_sync = [] {                                            // LDS traffic of ONE wave: in order, nothing to wait for
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // but the compiler must not move it
+        __builtin_amdgcn_wave_barrier();
+    };
+    // distance of point x to hyperplane h along its normal; true when within radius (mixtureGP.jl:361-367)
+    auto plane_t = [&](int h, const double *x, double *u, double &tt) -> bool {
 #pragma unroll
         for (int d = 0; d < D; ++d) u[d] = hv[h * D + d];
         const double c = hc[h];
-        const double tt = -dot_seq<D>(u, p, dot_mode) + c;       // mixtureGP.jl:361
-        double r0 = (p[0] + tt * u[0]) - p[0];                   // z = p + t.*u ; norm(z - p)   :362,:367
+        tt = -dot_seq<D>(u, x, dot_mode) + c;                        // :361
+        double r0 = (x[0] + tt * u[0]) - x[0];                       // z = p + t.*u ; norm(z - p)   :362,:367
         double s = r0 * r0;
 #pragma unroll
         for (int d = 1; d < D; ++d) {
-            double r = (p[d] + tt * u[d]) - p[d];
+            double r = (x[d] + tt * u[d]) - x[d];
             s = s + r * r;
         }
-        if (sqrt(s) < radius) {
-            const double tp = tt + delta, tm = tt - delta;
-            double z1[D], z2[D];
+        return s < r2lo || (s <= r2hi && sqrt(s) < radius);
+    };
+    // the two leaf searches behind an accepted distance test: the region across the plane, or -1 (:374-388)
+    auto across = [&](const double *x, const double *u, double tt, int hm) -> int {
+        const double tp = tt + delta, tm = tt - delta;
+        double z1[D], z2[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) { z1[d] = p[d] + tp * u[d]; z2[d] = p[d] + tm * u[d]; }
-            const int r1 = find_leaf<D>(hv, hc, levels, P, z1, dot_mode);   // :374-375
-            const int r2 = find_leaf<D>(hv, hc, levels, P, z2, dot_mode);
-            if ((r2 == home) != (r1 == home)) {                   // xor :388
+        for (int d = 0; d < D; ++d) { z1[d] = x[d] + tp * u[d]; z2[d] = x[d] + tm * u[d]; }
+        const int r1 = find_leaf<D>(hv, hc, levels, P, z1, dot_mode);
+        const int r2 = find_leaf<D>(hv, hc, levels, P, z2, dot_mode);
+        if ((r2 == hm) != (r1 == hm)) return (r1 == hm) ? r2 : r1;   // xor :388
+        return -1;
+    };
+    const int nn = (int)(P - 1);
+    for (int c0 = 0; c0 < nn; c0 += 256) {
+        const int c1 = min(nn, c0 + 256);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) bits[lane * 8 + w] = 0u;
+        int qn = 0;                                                  // queued candidates (the same in every lane)
+        auto run_batch = [&](int n) {                                // entries 0..n-1 of the queue, one per lane
+            wave_sync();
+            if (lane < n) {
+                const uint32_t ent = queue[lane];
+                const int src = (int)(ent & 255u), il = (int)(ent >> 8);
+                double xs[D], u[D], tt;
+#pragma unroll
+                for (int d = 0; d < D; ++d) xs[d] = qp[src * D + d];
+                (void)plane_t(pre[c0 + il], xs, u, tt);
+                if (across(xs, u, tt, qhome[src]) >= 0) atomicOr(&bits[src * 8 + (il >> 5)], 1u << (il & 31));
+            }
+            wave_sync();
+        };
+        for (int i = c0; i < c1; ++i) {
+            double u[D], tt;
+            const bool cand = plane_t(pre[i], p, u, tt) && valid;
+            const unsigned long long m = __ballot(cand);
+            if (m == 0ull) continue;
+            const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (cand) queue[qn + before] = (uint32_t)lane | ((uint32_t)(i - c0) << 8);
+            qn += __popcll(m);
+            if (qn >= 64) {
+                run_batch(64);
+                const uint32_t carry = lane < qn - 64 ? queue[64 + lane] : 0u;
+                wave_sync();
+                if (lane < qn - 64) queue[lane] = carry;
+                qn -= 64;
+            }
+        }
+        if (qn > 0) run_batch(qn);
+        // emit this lane's accepted planes in pre-order
+        for (int w = 0; w < 8; ++w) {
+            uint32_t mk = bits[lane * 8 + w];
+            while (mk) {
+                const int bpos = __builtin_ctz(mk);
+                mk &= mk - 1u;
+                double u[D], tt;
+                (void)plane_t(pre[c0 + 32 * w + bpos], p, u, tt);
+                const int reg = across(p, u, tt, home);
                 if (FILL) {
-                    item_region[base + count] = (r1 == home) ? r2 : r1;
+                    item_region[base + count] = reg;
                     item_t[base + count] = tt;
                     item_query[base + count] = (int32_t)j;
                 } else if (count < PLAN_STAGE) {
-                    stage_r[count * stage_ld + j] = (r1 == home) ? r2 : r1;
+                    stage_r[count * stage_ld + j] = reg;
                     stage_t[count * stage_ld + j] = tt;
                 }
                 ++count;
             }
         }
+        wave_sync();
     }
+    if (!valid) return;
     if (FILL) {
         item_region[base + count] = home;     // home region last (mixtureGP.jl:237-239)
         item_t[base + count] = 0.0;
@@ -220,7 +304,9 @@ static int launch_plan_D(pmk_query *q, double radius, double delta, bool fill, h
     dim3 grid((unsigned)((q->Nq + 255) / 256));
     const int64_t nn = m->P_global - 1;
     const bool lds = nn <= PLAN_LDS_NODES;
-    const size_t bytes = lds ? (size_t)nn * (D + 1) * sizeof(double) + (size_t)nn * sizeof(int32_t) : 0;
+    // the tree (when it fits) + the four waves' scratch (plan_kernel: WAVE_DOUBLES)
+    const size_t tree_doubles = lds ? (size_t)nn * (D + 1) + (size_t)(nn + 1) / 2 : 0;
+    const size_t bytes = sizeof(double) * (tree_doubles + 4 * (size_t)(64 * D + 32 + 256 + 64));
 #define PMK_PLAN(FILL_, LDS_)                                                                                          \
     hipLaunchKernelGGL((plan_kernel<D, FILL_, LDS_>), grid, dim3(256), bytes, s, q->Nq, q->d_xq, m->d_hv, m->d_hc,      \
                        m->d_pre, m->levels, m->dot_mode, m->P_global, radius, delta, q->d_home, q->d_cnt, q->d_qoff,                \
@@ -237,7 +323,7 @@ static int launch_plan_D(pmk_query *q, double radius, double delta, bool fill, h
 template <int D>
 static int set_plan_attributes_D()
 {
-    constexpr int bytes = PLAN_LDS_NODES * (D + 1) * 8 + PLAN_LDS_NODES * 4;
+    constexpr int bytes = 8 * (PLAN_LDS_NODES * (D + 1) + (PLAN_LDS_NODES + 1) / 2 + 4 * (64 * D + 32 + 256 + 64));
     PMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(plan_kernel<D, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     PMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(plan_kernel<D, false, true>),
