@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PMK_VERSION 102
+#define PMK_VERSION 103
 
 /* kernel families = the isbits kernel structs of src/misc/declarations.jl:18-45,65-67,75-111 */
 enum {
@@ -193,6 +193,9 @@ int  pmk_model_queryinner_ex(pmk_model *m, int64_t patch, const pmk_kernel_desc 
 /* replace the resident weights c_set (setupGPquery(c, X, theta, sigma2), querying.jl:43-59, takes c from its caller:
  * fit for the factor of K + sigma2 I, then put the caller's c in place) */
 int  pmk_model_set_weights(pmk_model *m, const double *const *c);
+/* all weight vectors at once: c[r] receives the n_r weights of patch r (one device-to-host transfer for the whole
+ * model; what fitmixtureGP! stores into c_set, mixtureGP.jl:106,115) */
+int  pmk_model_get_weights(pmk_model *m, double *const *c);
 
 /* ---- predict -------------------------------------------------------------------------- */
 /* attach the tree; this model holds the global leaves [leaf_base, leaf_base + P) */

@@ -464,8 +464,11 @@ function fitmixtureGP!(Î·::MixtureGPType{T}, y_parts::Vector{Vector{T}}, Î¸, ÏƒÂ
     Î·.U_set.n = Int.(n); Î·.L_set.n = Int.(n)
     bad = findfirst(!=(0), info)
     bad === nothing || throw(PosDefException(Int(info[bad])))       # cholesky(U) of mixtureGP.jl:109
+    cs = [Vector{Float64}(undef, Int(n[r])) for r = 1:P]          # every c_r in one device-to-host transfer
+    GC.@preserve cs check(ccall((:pmk_model_get_weights, libpmk), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}), Î·.model,
+                                [pointer(c) for c in cs]), "pmk_model_get_weights")
     for r = 1:P
-        Î·.c_set[r] = model_get(Î·.model, r, 0, Int(n[r]))
+        Î·.c_set[r] = cs[r]
         Î·.ÏƒÂ²_set[r] = ÏƒÂ²
         if store_factors
             Î·.L_set[r]; Î·.U_set[r]                                  # pulled and cached

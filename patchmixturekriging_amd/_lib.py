@@ -88,6 +88,7 @@ SIGNATURES = {
     "pmk_model_queryinner": (C.c_int, [_vp, C.c_int64, _kp, C.c_int64, _dp, _dp, _dp]),
     "pmk_model_queryinner_ex": (C.c_int, [_vp, C.c_int64, _kp, C.c_int64, _dp, C.c_double, _dp, _dp]),
     "pmk_model_set_weights": (C.c_int, [_vp, _dpp]),
+    "pmk_model_get_weights": (C.c_int, [_vp, _dpp]),
     "pmk_model_set_bsp": (C.c_int, [_vp, _vp, C.c_int64]),
     "pmk_query_create": (C.c_int, [_vp, C.c_int64, _dp, _vpp]),
     "pmk_query_create_items": (C.c_int, [_vp, C.c_int64, C.c_void_p, C.c_void_p, _vpp]),

@@ -823,9 +823,16 @@ int pmk_fit_batched(pmk_ctx *ctx, const pmk_kernel_desc *th, double sigma2, int 
     std::vector<int32_t> tmp((size_t)P);
     int st = pmk_model_info(*out, info ? info : tmp.data());
     if (st < 0) return st;
-    if (c_out)
-        for (int64_t r = 0; r < P; ++r)
-            if (c_out[r] && (rc = pmk_model_get(*out, r, PMK_GET_C, c_out[r], 0))) return rc;
+    if (c_out) {
+        bool every = true;
+        for (int64_t r = 0; r < P; ++r) every = every && c_out[r] != nullptr;
+        if (every) {
+            if ((rc = pmk_model_get_weights(*out, c_out))) return rc;
+        } else {
+            for (int64_t r = 0; r < P; ++r)
+                if (c_out[r] && (rc = pmk_model_get(*out, r, PMK_GET_C, c_out[r], 0))) return rc;
+        }
+    }
     return st;
 }
 
@@ -878,6 +885,22 @@ int pmk_model_set_weights(pmk_model *m, const double *const *c)
         std::vector<double> cc((size_t)d.ld, 0.0);
         std::memcpy(cc.data(), c[r], sizeof(double) * (size_t)d.n);
         if (int rc = upload_real(m, m->d_c, d.yoff, cc.data(), cc.size())) return rc;
+    }
+    return 0;
+}
+
+int pmk_model_get_weights(pmk_model *m, double *const *c)
+{
+    if (!m || !c) { set_error("pmk_model_get_weights: NULL argument"); return -1; }
+    if (!m->fitted) { set_error("pmk_model_get_weights: model is not fitted"); return -3; }
+    PMK_HIP(hipSetDevice(m->ctx->device));
+    // one transfer of the padded vector, then the patches' parts are cut out on the host
+    std::vector<double> all((size_t)std::max<int64_t>(m->tot_y, 1));
+    if (int rc = download_real_2d(m, all.data(), m->tot_y, m->d_c, 0, m->tot_y, m->tot_y, 1, m->ctx->stream)) return rc;
+    for (int64_t r = 0; r < m->P; ++r) {
+        const PatchDesc &d = m->desc[(size_t)r];
+        if (!c[r]) { set_error("pmk_model_get_weights: output of patch %lld is NULL", (long long)r); return -2; }
+        std::memcpy(c[r], all.data() + d.yoff, sizeof(double) * (size_t)d.n);
     }
     return 0;
 }

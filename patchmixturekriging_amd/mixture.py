@@ -117,6 +117,13 @@ class DeviceModel:
         _lib.check(self.ctx.L.pmk_model_info(self.h, info.ctypes.data_as(C.POINTER(C.c_int32))), "pmk_model_info")
         return info
 
+    def weights(self):
+        """c_set: the weights of every patch, one device-to-host transfer for the whole model"""
+        out = [np.empty(int(n)) for n in self.n]
+        PA = _dp * self.P
+        _lib.check(self.ctx.L.pmk_model_get_weights(self.h, PA(*[_d(c) for c in out])), "pmk_model_get_weights")
+        return out
+
     def get(self, patch, what):
         n = int(self.n[patch])
         if what == GET_C:
@@ -265,7 +272,7 @@ def fit_patches(X_parts, y_parts, theta, sigma2, ctx=None, dtype="f64"):
         model.set_diag([theta.diag_addend(x) for x in X_parts])
     model.fit(theta, sigma2)
     info = model.info()
-    cs = [model.get(r, GET_C) for r in range(model.P)]
+    cs = model.weights()
     return model, cs, info
 
 

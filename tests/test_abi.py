@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(decl):
         assert hasattr(L, name), name
     assert decl == set(_lib.SIGNATURES), decl ^ set(_lib.SIGNATURES)
-    assert L.pmk_version() == 102
+    assert L.pmk_version() == 103
 
 
 def test_product_does_not_import_the_oracle():
