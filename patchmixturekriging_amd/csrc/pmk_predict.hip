@@ -299,10 +299,15 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
                 const real *Li = S + (int64_t)i * TILE;
                 const real *Lii = Li + (int64_t)i * TILE * ld;
                 const real *ninv_i = inv + pd.ioff + (int64_t)i * 4096;
+#ifdef PMK_PRED_ONE_VARIANT
+                // experiment: one GEMM call site (the last block row computes its identity padding along)
+                strip_block_row<4>(acc, Li, ld, V, i, Lii, ninv_i, lane, PMK_TRACED);
+#else
                 if (i + 1 == pd.nt && last_pairs == 3) strip_block_row<3>(acc, Li, ld, V, i, Lii, ninv_i, lane, PMK_TRACED);
                 else if (i + 1 == pd.nt && last_pairs == 2) strip_block_row<2>(acc, Li, ld, V, i, Lii, ninv_i, lane, PMK_TRACED);
                 else if (i + 1 == pd.nt && last_pairs == 1) strip_block_row<1>(acc, Li, ld, V, i, Lii, ninv_i, lane, PMK_TRACED);
                 else strip_block_row<4>(acc, Li, ld, V, i, Lii, ninv_i, lane, PMK_TRACED);
+#endif
                 PMK_PSTAMP(4);
                 {
                     real vs[NC];
