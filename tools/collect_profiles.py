@@ -20,6 +20,8 @@ def main():
                  ("bench_C.json", "bench_C.json"), ("ragged_bench.json", "ragged_bench.json"),
                  ("config_E_fp32_bench.json", "config_E_fp32_bench.json"),
                  ("config_D_one_gpu_bench.json", "config_D_one_gpu_bench.json"),
+                 ("config_E_fp32_unfused_bench.json", "config_E_fp32_unfused_bench.json"),
+                 ("single_problem.json", "single_problem.json"), ("e2e_breakdown.txt", "e2e_breakdown.txt"),
                  ("pmc/summary.json", "pmc_summary.json"), ("commands.txt", "pmc_commands.txt")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (dst_tag, b)))

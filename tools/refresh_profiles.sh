@@ -19,4 +19,8 @@ python3 bench.py > "$out/bench_C.json" 2> "$out/bench_C.log"
 python3 bench.py --n 1616 --eps 0.044 --no-cpu > "$out/ragged_bench.json" 2> "$out/ragged.log"
 python3 bench.py --config E --no-cpu --steps 3 --warmup 1 > "$out/config_E_fp32_bench.json" 2> "$out/E.log"
 python3 bench.py --config D --patches 1024 --nq 4194304 --no-cpu --steps 3 --warmup 1 > "$out/config_D_one_gpu_bench.json" 2> "$out/D.log"
+# the HBM-bound kernel-matrix build of config E on its own (the default fit evaluates the tiles inside the factorisation)
+PMK_FUSE_K1=0 python3 bench.py --config E --no-cpu --no-e2e --steps 3 --warmup 1 > "$out/config_E_fp32_unfused_bench.json" 2> "$out/E_unfused.log"
+SP_JSON="$out/single_problem.json" python3 tools/single_problem.py > "$out/single_problem.log" 2>&1
+python3 tools/e2e_breakdown.py > "$out/e2e_breakdown.txt" 2>&1
 tail -c 600 "$out/bench_C.json"
