@@ -31,7 +31,9 @@ int pmk_selftest_mfma_peak(pmk_ctx *ctx, double *tflops);
 int pmk_test_comm_force_exchange(pmk_comm *comm, int on);
 
 /* choose the factorisation path of a model by hand: 0 = one workgroup per block row (batched), 1 = split path (deep
- * products cut along K, block-wise triangular solves); pmk_model_create picks by itself from P and the tile counts */
+ * products cut along K; the triangular solves as one chained launch each where the blocks nearly fit on the chip, block
+ * by block otherwise), 2 = split path with the block-by-block solves, 3 = split path with the chained solves whatever
+ * the size; pmk_model_create picks by itself from P and the tile counts */
 int pmk_test_model_set_split(pmk_model *model, int on);
 
 #ifdef __cplusplus

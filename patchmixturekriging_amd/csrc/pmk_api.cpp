@@ -647,6 +647,7 @@ int pmk_test_model_set_split(pmk_model *m, int on)
 {
     if (!m) { set_error("pmk_test_model_set_split: model is NULL"); return -1; }
     m->split_mode = on != 0 && m->max_nt >= 2;
+    m->chain_mode = on == 2 ? 0 : on == 3 ? 1 : -1;
     return 0;
 }
 

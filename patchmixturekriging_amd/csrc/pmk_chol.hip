@@ -1616,7 +1616,8 @@ static int launch_split_solves(pmk_model *m, hipStream_t s)
     const int P = (int)m->P;
     // one chained launch per solve when the patches' blocks (nearly) fit on the chip together, else block by block
     static const char *chain_env = std::getenv("PMK_SPLIT_CHAIN");
-    const bool chain = chain_env ? std::atoi(chain_env) != 0 : (int64_t)P * m->max_nt <= 2 * (int64_t)m->ctx->num_cu;
+    const bool chain = m->chain_mode >= 0 ? m->chain_mode != 0
+                       : chain_env ? std::atoi(chain_env) != 0 : (int64_t)P * m->max_nt <= 2 * (int64_t)m->ctx->num_cu;
     m->chain_used = chain;
     if (chain) {
         const size_t words = 16 + 2 * (size_t)P * (size_t)m->max_nt;          // error word, flags of z, flags of c

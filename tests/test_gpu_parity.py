@@ -983,6 +983,36 @@ def test_split_path_matches_batched_path_and_lapack(P, n, D):
     assert np.array_equal(auto.get(0, M.GET_C), out[1 if n == 8192 else 0][0][1])
 
 
+def test_chained_solves_with_more_blocks_than_compute_units():
+    """solve_chain_kernel (both triangular solves of the split path as one launch each: a block's workgroup waits for
+    flag words set by workgroups with lower ids) with MORE workgroups than fit on the chip at once -- 9 patches x 33
+    blocks = 297 workgroups of 512 threads and 84-92 KB of LDS, one per CU, 256 CUs: the later ones are dispatched as
+    earlier ones retire.  Against the block-by-block solves on the same factor (other summation order: ~cond eps), ragged
+    sizes included, three fits in a row (the flags carry the launch's epoch, nothing is cleared in between)."""
+    rng = np.random.Generator(np.random.PCG64(4242))
+    sizes = [4224 - 128 * (r % 3) - 7 * r for r in range(9)]
+    Xs = [rng.uniform(0, 1, (m, 2)) for m in sizes]
+    ys = [np.sin(3 * x[:, 0]) + x[:, 1] ** 2 for x in Xs]
+    th = pmk.Spline34KernelType(3.0)
+    ctx = pmk.default_context()
+    out = {}
+    for mode in (2, 3):                               # pmk_test.h: split path with block-by-block / chained solves
+        m = pmk.DeviceModel(Xs, ys)
+        assert ctx.L.pmk_test_model_set_split(m.h, mode) == 0
+        for _ in range(3):
+            m.fit(th, 1e-5)
+            assert np.all(m.info() == 0)
+        out[mode] = m.weights()
+        if mode == 3:
+            L0 = m.get(0, M.GET_L)
+    for r in range(9):
+        assert np.linalg.norm(out[3][r] - out[2][r]) / np.linalg.norm(out[2][r]) < 1e-8
+    import scipy.linalg as sla                         # and the chained result against LAPACK solves on the device's factor
+    z = sla.solve_triangular(L0, ys[0], lower=True, check_finite=False)
+    c = sla.solve_triangular(L0, z, lower=True, trans="T", check_finite=False)
+    assert np.abs(out[3][0] - c).max() <= 1e-9 * np.abs(c).max()
+
+
 # ------------------------------------------------------------------------------------ SURVEY 8(f) ranks 3 and 4, row 17 remainder
 def test_gp_query_with_variance_vs_reference_formula():
     """setupGPquery / evalqueryGP! (src/RKHS/querying.jl:43-79): mean = c . k, variance = k(x,x) - k' (A \\ k) with
