@@ -1,5 +1,4 @@
 // K1 (kernel-matrix build), K5 (query-side BSP search + item list), K6 (mixture) and small helpers.
-#include <hipcub/hipcub.hpp>
 
 #include "pmk_device.h"
 
@@ -350,25 +349,102 @@ static int launch_plan(pmk_query *q, double radius, double delta, bool fill, hip
 int launch_plan_count(pmk_query *q, double radius, double delta, hipStream_t s) { return launch_plan(q, radius, delta, false, s); }
 int launch_plan_fill(pmk_query *q, double radius, double delta, hipStream_t s) { return launch_plan(q, radius, delta, true, s); }
 
-struct CastI64 {
-    __host__ __device__ int64_t operator()(int32_t v) const { return (int64_t)v; }
-};
+// ---------------------------------------------------------------------------------------------
+// Exclusive prefix sums of the per-query item counts: d_out[i] = sum of d_in[0..i), i = 0..n (n + 1 outputs; d_in needs
+// n + 1 readable entries, the last one is ignored).  Three small launches: sums of 2048-entry blocks, their scan by one
+// workgroup, the blocks again with their offsets.
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_PER_THREAD = 8, SCAN_BLOCK = 256 * SCAN_PER_THREAD;
 
-// d_out[0..n] = exclusive prefix sums of d_in[0..n) (d_out has n+1 entries); d_in needs n+1 readable
-// entries, the last one is ignored.
+// sum over the workgroup of one value per thread (256 threads); result in every thread
+__device__ __forceinline__ int64_t block_sum_256(int64_t v, int64_t *red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t *__restrict__ in, int64_t n, int64_t *__restrict__ bsum)
+{
+    __shared__ int64_t red[4];
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_PER_THREAD;
+    int64_t v = 0;
+#pragma unroll
+    for (int u = 0; u < SCAN_PER_THREAD; ++u)
+        if (i0 + u < n) v += in[i0 + u];
+    v = block_sum_256(v, red);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = v;
+}
+
+// in place: bsum[b] <- sum of bsum[0..b); one workgroup, 256 entries at a time
+__global__ __launch_bounds__(256) void scan_offsets_kernel(int64_t *__restrict__ bsum, int64_t nb)
+{
+    __shared__ int64_t sh[256];
+    int64_t carry = 0;
+    for (int64_t b0 = 0; b0 < nb; b0 += 256) {
+        const int64_t b = b0 + threadIdx.x;
+        const int64_t mine = b < nb ? bsum[b] : 0;
+        sh[threadIdx.x] = mine;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {                  // inclusive scan (Hillis-Steele)
+            const int64_t add = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (b < nb) bsum[b] = carry + sh[threadIdx.x] - mine;
+        carry += sh[255];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t *__restrict__ in, int64_t n, const int64_t *__restrict__ boff,
+                                                         int64_t *__restrict__ out)
+{
+    __shared__ int64_t sh[256];
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_PER_THREAD;
+    int32_t v[SCAN_PER_THREAD];
+    int64_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < SCAN_PER_THREAD; ++u) {
+        v[u] = i0 + u < n ? in[i0 + u] : 0;
+        mine += v[u];
+    }
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int64_t add = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int64_t run = boff[blockIdx.x] + sh[threadIdx.x] - mine;
+#pragma unroll
+    for (int u = 0; u < SCAN_PER_THREAD; ++u) {
+        if (i0 + u <= n) out[i0 + u] = run;                  // n + 1 outputs
+        run += v[u];
+    }
+}
+
 int64_t exclusive_scan_i32_to_i64(const int32_t *d_in, int64_t *d_out, int64_t n, void **tmp, size_t *tmp_bytes,
                                   hipStream_t s)
 {
-    hipcub::TransformInputIterator<int64_t, CastI64, const int32_t *> it(d_in, CastI64());
-    size_t need = 0;
-    if (hipcub::DeviceScan::ExclusiveSum(nullptr, need, it, d_out, (int)(n + 1), s) != hipSuccess) return -1;
+    const int64_t nb = (n + 1 + SCAN_BLOCK - 1) / SCAN_BLOCK;          // blocks over the n + 1 outputs
+    const size_t need = sizeof(int64_t) * (size_t)nb;
     if (need > *tmp_bytes) {
         if (*tmp) (void)hipFree(*tmp);
+        *tmp = nullptr; *tmp_bytes = 0;
         if (hipMalloc(tmp, need) != hipSuccess) return -1;
         *tmp_bytes = need;
     }
-    if (hipcub::DeviceScan::ExclusiveSum(*tmp, need, it, d_out, (int)(n + 1), s) != hipSuccess) return -1;
-    return 0;
+    int64_t *bsum = reinterpret_cast<int64_t *>(*tmp);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, s, d_in, n, bsum);
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(256), 0, s, bsum, nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, d_in, n, (const int64_t *)bsum, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 __global__ void iota_kernel(int32_t *v, int64_t n)
@@ -385,52 +461,164 @@ int launch_iota(int32_t *d, int64_t n, hipStream_t s)
     return 0;
 }
 
-// region_offsets from the sorted keys + the inverse permutation
-__global__ void region_offsets_kernel(const int32_t *__restrict__ keys, const int32_t *__restrict__ sorted_item,
-                                      int64_t n, int64_t P, int64_t *__restrict__ roff, int32_t *__restrict__ item_pos)
+// ---------------------------------------------------------------------------------------------
+// Stable counting sort of the items by region (keys < P, a few thousand at most): sorted_item[pos] = item,
+// item_pos[item] = pos, roff[r] = first position of region r (roff[P] = n).  Deterministic, so every rank of a multi-GPU
+// job derives the same order from a replicated plan.  Items are cut into blocks of `bitems` consecutive items:
+//   sort_hist_kernel     hist[r][b]  = items of region r in block b
+//   sort_scan_kernel     hist[r][b] <- items of region r in blocks < b ; total[r]    (one wave per region)
+//   sort_roff_kernel     roff[r]     = items of regions < r                          (one workgroup)
+//   sort_scatter_kernel  one wave per block walks its items 64 at a time in order: the lanes that hold the same region
+//                        form a group (found with ballots over the distinct regions of the tile), a lane's rank in its
+//                        group is its position in it, the group's first lane takes the group's base with ONE atomic add
+//                        on hist[r][b] -- all groups of a tile at once -- and hands it to the others
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sort_hist_kernel(const int32_t *__restrict__ key, int64_t n, int bitems, int64_t nb,
+                                                        int64_t P, int32_t *__restrict__ hist)
 {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= n) return;
-    item_pos[sorted_item[k]] = (int32_t)k;
-    const int cur = keys[k];
-    const int prev = (k == 0) ? -1 : keys[k - 1];
-    for (int r = prev + 1; r <= cur; ++r) roff[r] = k;
-    if (k == n - 1)
-        for (int64_t r = cur + 1; r <= P; ++r) roff[r] = n;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = key[i];
+    if ((unsigned)k >= (unsigned)P) return;                 // an invalid region of an explicit item list (reported by its check)
+    atomicAdd(&hist[(int64_t)k * nb + i / bitems], 1);
 }
 
-// stable sort of the items by region: deterministic, so every rank of a multi-GPU job derives the
-// same sorted order from the replicated plan
+// the same with the block's histogram in LDS (P <= SORT_LDS_BINS): one workgroup per block of items, no memset before
+constexpr int SORT_LDS_BINS = 8192;
+__global__ __launch_bounds__(256) void sort_hist_lds_kernel(const int32_t *__restrict__ key, int64_t n, int bitems, int64_t nb,
+                                                            int64_t P, int32_t *__restrict__ hist)
+{
+    extern __shared__ int32_t sort_bins[];
+    for (int r = threadIdx.x; r < (int)P; r += 256) sort_bins[r] = 0;
+    __syncthreads();
+    const int64_t b = blockIdx.x, i0 = b * bitems, i1 = min(n, i0 + (int64_t)bitems);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int k = key[i];
+        if ((unsigned)k < (unsigned)P) atomicAdd(&sort_bins[k], 1);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < (int)P; r += 256) hist[(int64_t)r * nb + b] = sort_bins[r];
+}
+
+__global__ __launch_bounds__(256) void sort_scan_kernel(int32_t *__restrict__ hist, int64_t nb, int64_t P, int32_t *__restrict__ total)
+{
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= P) return;
+    int32_t *h = hist + r * nb;
+    int32_t carry = 0;
+    for (int64_t b0 = 0; b0 < nb; b0 += 64) {
+        const int64_t b = b0 + lane;
+        const int32_t mine = b < nb ? h[b] : 0;
+        int32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (b < nb) h[b] = carry + inc - mine;
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0) total[r] = carry;
+}
+
+__global__ __launch_bounds__(256) void sort_roff_kernel(const int32_t *__restrict__ total, int64_t P, int64_t *__restrict__ roff)
+{
+    __shared__ int64_t sh[256];
+    int64_t carry = 0;
+    for (int64_t r0 = 0; r0 < P; r0 += 256) {
+        const int64_t r = r0 + threadIdx.x;
+        const int64_t mine = r < P ? total[r] : 0;
+        sh[threadIdx.x] = mine;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int64_t add = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (r < P) roff[r] = carry + sh[threadIdx.x] - mine;
+        carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) roff[P] = carry;
+}
+
+__global__ __launch_bounds__(64) void sort_scatter_kernel(const int32_t *__restrict__ key, int64_t n, int bitems, int64_t nb,
+                                                          int64_t P, int32_t *__restrict__ hist, const int64_t *__restrict__ roff,
+                                                          int32_t *__restrict__ sorted_item, int32_t *__restrict__ item_pos)
+{
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x, i0 = b * bitems, i1 = min(n, i0 + (int64_t)bitems);
+    // one tile behind: the atomic adds of tile t are in flight while the groups of tile t + 1 are formed
+    int64_t pi = 0, proff = 0;
+    int32_t pbase = 0;
+    int prank = 0, pleader = 0;
+    bool pvalid = false;
+    for (int64_t t0 = i0; t0 < i1 + 64; t0 += 64) {
+        const int64_t i = t0 + lane;
+        const int k = i < i1 ? key[i] : -1;
+        const bool valid = (unsigned)k < (unsigned)P;       // invalid regions are left out (see sort_hist_kernel)
+        // groups of equal keys: rank of the lane in its group, the group's size and first lane
+        int rank = 0, cnt = 0, leader = lane;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int first = __builtin_ctzll(todo);
+            const int kf = __shfl(k, first);
+            const unsigned long long grp = __ballot(valid && k == kf);
+            if (k == kf && valid) {
+                rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(grp >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)grp, 0u));
+                cnt = __popcll(grp);
+                leader = first;
+            }
+            todo &= ~grp;
+        }
+        const int64_t ro = valid ? roff[k] : 0;
+        // finish the previous tile: its atomic adds have had the time of the loop above to return
+        const int32_t pb = __shfl(pbase, pleader);
+        if (pvalid) {
+            const int64_t pos = proff + pb + prank;
+            sorted_item[pos] = (int32_t)pi;
+            item_pos[pi] = (int32_t)pos;
+        }
+        // this tile's groups take their bases only now, behind the previous tile's returned values: a later tile gets the
+        // later base
+        int32_t base = 0;
+        if (valid && lane == leader) base = atomicAdd(&hist[(int64_t)k * nb + b], cnt);     // items of this region placed so far
+        pi = i; proff = ro; pbase = base; prank = rank; pleader = leader; pvalid = valid;
+    }
+}
+
 int launch_sort_items(pmk_query *q, hipStream_t s)
 {
     const int64_t n = q->total;
     const pmk_model *m = q->m;
     if (n == 0) return 0;
-    // scratch for the sorted keys and the identity permutation, kept with the query (grow only)
-    if (q->sort_cap < n) {
+    const int64_t P = m->P_global;
+    // block length: at least two items per region and block on average, so that the histogram stays smaller than the items
+    const int bitems = (int)std::max<int64_t>(1024, 64 * ((2 * P + 63) / 64));
+    const int64_t nb = (n + bitems - 1) / bitems;
+    const int64_t words = P * nb + P + 64;                   // hist[P][nb], total[P]
+    if (q->sort_cap < words) {
         if (q->d_sort_scratch) PMK_HIP(hipFree(q->d_sort_scratch));
         q->d_sort_scratch = nullptr;
         q->sort_cap = 0;
-        PMK_HIP(hipMalloc(&q->d_sort_scratch, sizeof(int32_t) * 2 * (size_t)(n + n / 8 + 1024)));
-        q->sort_cap = n + n / 8 + 1024;
+        PMK_HIP(hipMalloc(&q->d_sort_scratch, sizeof(int32_t) * (size_t)(words + words / 8)));
+        q->sort_cap = words + words / 8;
     }
-    int32_t *keys_out = reinterpret_cast<int32_t *>(q->d_sort_scratch);
-    int32_t *iota = keys_out + q->sort_cap;
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, iota, n);
-    int bits = 1;
-    while (((int64_t)1 << bits) < m->P_global) ++bits;
-    size_t need = 0;
-    PMK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, q->d_item_region, keys_out, iota, q->d_sorted_item, (int)n,
-                                               0, bits, s));
-    if (need > q->tmp_bytes) {
-        if (q->d_tmp) PMK_HIP(hipFree(q->d_tmp));
-        PMK_HIP(hipMalloc(&q->d_tmp, need));
-        q->tmp_bytes = need;
+    int32_t *hist = reinterpret_cast<int32_t *>(q->d_sort_scratch);
+    int32_t *total = hist + P * nb;
+    if (P <= SORT_LDS_BINS) {
+        hipLaunchKernelGGL(sort_hist_lds_kernel, dim3((unsigned)nb), dim3(256), sizeof(int32_t) * (size_t)P, s, q->d_item_region, n,
+                           bitems, nb, P, hist);
+    } else {
+        PMK_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)(P * nb), s));
+        hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q->d_item_region, n, bitems, nb, P, hist);
     }
-    PMK_HIP(hipcub::DeviceRadixSort::SortPairs(q->d_tmp, need, q->d_item_region, keys_out, iota, q->d_sorted_item, (int)n,
-                                               0, bits, s));
-    hipLaunchKernelGGL(region_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys_out,
-                       q->d_sorted_item, n, m->P_global, q->d_roff, q->d_item_pos);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, s, hist, nb, P, total);
+    hipLaunchKernelGGL(sort_roff_kernel, dim3(1), dim3(256), 0, s, total, P, q->d_roff);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)nb), dim3(64), 0, s, q->d_item_region, n, bitems, nb, P, hist,
+                       (const int64_t *)q->d_roff, q->d_sorted_item, q->d_item_pos);
     PMK_HIP(hipGetLastError());
     return 0;
 }

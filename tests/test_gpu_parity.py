@@ -627,6 +627,33 @@ def test_sharded_models_match_single_model():
     empty.export_results(None, None)
 
 
+def test_item_sort_is_a_stable_counting_sort():
+    """the hand-written sort of the items by region (pmk_kernels.hip: block histograms, per-region scan, one wave per block
+    ranking equal regions by ballots) is STABLE: explicit items with random regions and x = the item's own index come back
+    (pmk_query_export_requests, sorted order) with non-decreasing regions and increasing indices inside each region;
+    sizes around the 64-item tile and the 1024-item block of the kernel, a single region, every region"""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(99))
+    X = rng.uniform(-1, 1, (4096, 2))
+    root, X_parts, inds = pmk.setuppartition(X, 6)                       # 32 leaves
+    P = len(X_parts)
+    y = np.sin(X.sum(1))
+    m = pmk.DeviceModel(X_parts, [y[i] for i in inds]); m.fit(pmk.Spline34KernelType(2.0), 1e-3); m.set_bsp(root, 0)
+    for n, nreg in ((1, P), (63, P), (64, P), (65, P), (1023, P), (1024, 3), (1025, P), (5000, 1), (70001, P)):
+        reg = rng.integers(0, nreg, n).astype(np.int32)
+        xs = np.stack([np.arange(n, dtype=np.float64), np.zeros(n)], axis=1)
+        q = pmk.DeviceQuery.from_items(m, n, xs.ctypes.data, reg.ctypes.data)
+        off = q.region_offsets(P)
+        assert np.array_equal(np.diff(off), np.bincount(reg, minlength=P))
+        xo = torch.empty((n, 2), dtype=torch.float64, device="cuda")
+        ro = torch.empty(n, dtype=torch.int32, device="cuda")
+        q.export_requests(0, n, xo.data_ptr(), ro.data_ptr())
+        pmk.default_context().synchronize()
+        order = xo[:, 0].cpu().numpy().astype(np.int64)
+        assert np.array_equal(order, np.argsort(reg, kind="stable"))
+        assert np.array_equal(ro.cpu().numpy(), reg[order])
+
+
 @pytest.mark.timeout(1500)
 def test_config_D_workload_one_gpu_sharded_8_ways():
     """BASELINE config D's workload (2-D mixGP, levels = 11 -> 1024 BSP patches x 2000 points, fp64: 34 GB of slabs) on
