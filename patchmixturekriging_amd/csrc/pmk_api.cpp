@@ -720,7 +720,7 @@ int pmk_model_info(pmk_model *m, int32_t *info)
         PMK_HIP(hipMemcpyAsync(&chain_err, m->d_chain, sizeof(int32_t), hipMemcpyDeviceToHost, m->ctx->stream));
     PMK_HIP(hipStreamSynchronize(m->ctx->stream));
     if (chain_err != 0) {
-        // solve_back_chain_kernel: a block waited 3 s for the block above it (never seen; bounded so that a fault ends)
+        // solve_chain_kernel: a block waited 3 s for the block it depends on (never seen; bounded so that a fault ends)
         PMK_HIP(hipMemsetAsync(m->d_chain, 0, sizeof(int32_t), m->ctx->stream));
         set_error("pmk_model_fit: the chained back substitution timed out waiting for block %d", (int)chain_err - 1);
         return -4;

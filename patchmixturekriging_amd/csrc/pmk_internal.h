@@ -120,7 +120,7 @@ struct pmk_model {
     int qfstride = 0;
     void *d_partial = nullptr; size_t partial_bytes = 0;      // partial product tiles of one step
     void *d_solve_part = nullptr; size_t solve_bytes = 0;     // partial matrix-vector products of one solve block
-    void *d_chain = nullptr; size_t chain_words = 0;          // solve_back_chain_kernel: error word, then one flag word per block
+    void *d_chain = nullptr; size_t chain_words = 0;          // solve_chain_kernel: error word, then one flag word per block and direction
     int chain_epoch = 0; bool chain_used = false;             // the flags hold the epoch of the launch that set them
     int chain_mode = -1;                                      // -1: by size, 0: block-by-block solves, 1: chained solves (pmk_test.h)
     int64_t tot_a = 0, tot_x = 0, tot_y = 0, tot_inv = 0;
