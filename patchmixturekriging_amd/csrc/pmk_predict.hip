@@ -194,7 +194,15 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
     if (clk && blockIdx.x < 8 && threadIdx.x == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     real *V = strips + (int64_t)blockIdx.x * strip_stride + WCOLS * wave;   // this wave's columns, ld = TQ
     constexpr int PTS = (MAX_D + 1) * TILE;
-    __shared__ real pts[3 * PTS];             // training points (SoA) and weights of three consecutive block rows
+    // training points (SoA) and weights of consecutive block rows: a ring of three with one barrier per block row, of six
+    // with one barrier every second block row (PMK_PRED_SYNC2: the older wave of a SIMD then goes straight on into its next
+    // GEMM on odd rows instead of waiting for the younger one's block substitution)
+#ifdef PMK_PRED_SYNC2
+    constexpr int RING = 6;
+#else
+    constexpr int RING = 3;
+#endif
+    __shared__ real pts[RING * PTS];
     __shared__ real priv[PRED_WAVES * 8 * 64 * 2 * NPJW];   // lane-private staging of the kernel evaluations (8 slots a lane)
     kvec_t *mine = reinterpret_cast<kvec_t *>(priv) + (wave * 8) * 64 + lane;
     // Per-thread values that are only needed between the MFMA phases (the two query points, the running means and
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
         };
         // the training points and weights of block row `br`, the same for every lane of the workgroup, by 128 threads
         auto stage_points = [&](int br, int t) {
-            real *dst = pts + (br % 3) * PTS;
+            real *dst = pts + (br % RING) * PTS;
             const int row = br * TILE + t;
 #pragma unroll
             for (int d = 0; d < D; ++d) dst[d * TILE + t] = xs[(int64_t)d * ld + row];
@@ -279,16 +287,31 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
         const int last_pairs = (pd.n - (pd.nt - 1) * TILE + 31) >> 5;
 
         __syncthreads();                              // every wave is done with the previous task's points
+#ifdef PMK_PRED_SYNC2
+        if ((int)(threadIdx.x >> 7) < pd.nt) stage_points(threadIdx.x >> 7, threadIdx.x & (TILE - 1));       // rows 0..3
+#else
         if (threadIdx.x < 2 * TILE && (int)(threadIdx.x >> 7) < pd.nt) stage_points(threadIdx.x >> 7, threadIdx.x & (TILE - 1));
+#endif
         if (threadIdx.x == 0 && tk.group >= 0) rendezvous(0);
         WaveTile<4, NPJW> acc;
         bool have = false;                            // acc already holds this block row's kernel tile
         for (int i = 0; i < pd.nt; ++i) {
+#ifdef PMK_PRED_SYNC2
+            // even rows only: rows i .. i + 3 were staged before the barrier before this one; rows i + 4, i + 5 go into the
+            // slots of rows i - 2, i - 1, which every wave has left behind
+            if ((i & 1) == 0) {
+                __syncthreads();
+                if (threadIdx.x < 2 * TILE && i + 4 + (int)(threadIdx.x >> 7) < pd.nt)
+                    stage_points(i + 4 + (int)(threadIdx.x >> 7), threadIdx.x & (TILE - 1));
+            }
+            PMK_PSTAMP(0);
+#else
             __syncthreads();                          // block row i - 1 is complete in every wave; points of row i, i + 1 visible
             PMK_PSTAMP(0);
             if (threadIdx.x < TILE && i + 2 < pd.nt) stage_points(i + 2, threadIdx.x);
+#endif
             if (active) {
-                if (!have) eval_tile<D, FAM>(acc, pts + (i % 3) * PTS, mine, pk, th, i * TILE, pd.n, lane);
+                if (!have) eval_tile<D, FAM>(acc, pts + (i % RING) * PTS, mine, pk, th, i * TILE, pd.n, lane);
                 PMK_PSTAMP(2);
 #ifdef PMK_TRACE
                 if (round == PMK_TRACE_ROUND && i == PMK_TRACE_ROW && lane == 0 && blockIdx.x < 64)
@@ -341,7 +364,7 @@ __global__ __launch_bounds__(PRED_THREADS, NPJW == 1 ? 2 : 1) void predict_strip
                         }
                     PMK_PSTAMP(5);
                     if (NPJW == 1 && wave < PRED_WAVES / 2) {      // the older wave of its SIMD: next tile now, in its idle time
-                        eval_tile<D, FAM>(acc, pts + ((i + 1) % 3) * PTS, mine, pk, th, (i + 1) * TILE, pd.n, lane);
+                        eval_tile<D, FAM>(acc, pts + ((i + 1) % RING) * PTS, mine, pk, th, (i + 1) * TILE, pd.n, lane);
                         have = true;
                     }
                 }
