@@ -991,11 +991,9 @@ int pmk_model_set_bsp(pmk_model *m, const pmk_bsp *bsp, int64_t leaf_base)
 void pmk_query_destroy(pmk_query *q)
 {
     if (!q) return;
-    dev_free(q->d_xq); dev_free(q->d_qdiag); dev_free(q->d_home); dev_free(q->d_cnt); dev_free(q->d_qoff);
-    dev_free(q->d_stage_r); dev_free(q->d_stage_t);
-    dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
-    dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_roff);
-    dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w); dev_free(q->d_yq); dev_free(q->d_vq); dev_free(q->d_flag);
+    // d_xq and d_item_t are the bases of the two arenas (query_reserve, grow_item_buffers): the other per-point and
+    // per-item pointers live inside them
+    dev_free(q->d_xq); dev_free(q->d_item_t); dev_free(q->d_qdiag); dev_free(q->d_roff); dev_free(q->d_flag);
     if (q->d_tmp) (void)hipFree(q->d_tmp);
     if (q->d_sort_scratch) (void)hipFree(q->d_sort_scratch);
     if (q->d_tasks) (void)hipFree(q->d_tasks);
@@ -1007,27 +1005,39 @@ void pmk_query_destroy(pmk_query *q)
 
 namespace pmk {
 
-// per-query-point buffers for up to Nq points, grow only
+// One device allocation cut into 256-byte aligned pieces: a query object used to own two dozen small buffers, and every
+// hipFree is a device synchronisation (pmk_query_destroy: 3.4 ms of a 108 ms querymixtureGP! at config C).
+struct ArenaLayout {
+    size_t bytes = 0;
+    size_t add(size_t n) { const size_t at = bytes; bytes = (bytes + n + 255) & ~(size_t)255; return at; }
+};
+
+// per-query-point buffers for up to Nq points, grow only.  ONE allocation; d_xq is its base (the only pointer freed).
 int query_reserve(pmk_query *q, int64_t Nq)
 {
     pmk_model *m = q->m;
     if (Nq <= q->nq_cap) return 0;
     const bool regrow = q->nq_cap > 0;
-    dev_free(q->d_xq); dev_free(q->d_home); dev_free(q->d_cnt); dev_free(q->d_qoff); dev_free(q->d_yq); dev_free(q->d_vq);
-    dev_free(q->d_stage_r); dev_free(q->d_stage_t);
+    dev_free(q->d_xq);
+    q->d_home = nullptr; q->d_cnt = nullptr; q->d_qoff = nullptr; q->d_yq = nullptr; q->d_vq = nullptr;
+    q->d_stage_r = nullptr; q->d_stage_t = nullptr;
     q->nq_cap = 0;
-    const int64_t cap = Nq + (regrow ? Nq / 8 : 0);
-    int rc = 0;
-    rc |= dev_alloc(&q->d_xq, cap * m->D);
-    rc |= dev_alloc(&q->d_home, cap);
-    rc |= dev_alloc(&q->d_cnt, cap + 1);
-    rc |= dev_alloc(&q->d_stage_r, 4 * cap);          // PLAN_STAGE rows (pmk_kernels.hip)
-    rc |= dev_alloc(&q->d_stage_t, 4 * cap);
-    rc |= dev_alloc(&q->d_qoff, cap + 1);
-    rc |= dev_alloc(&q->d_yq, cap);
-    rc |= dev_alloc(&q->d_vq, cap);
-    if (rc) return -100;
-    q->nq_cap = cap;
+    const size_t cap = (size_t)(Nq + (regrow ? Nq / 8 : 0)), c1 = std::max<size_t>(cap, 1);
+    ArenaLayout a;
+    const size_t o_xq = a.add(sizeof(double) * c1 * (size_t)m->D), o_st = a.add(sizeof(double) * 4 * c1),      // PLAN_STAGE rows
+                 o_yq = a.add(sizeof(double) * c1), o_vq = a.add(sizeof(double) * c1), o_qoff = a.add(sizeof(int64_t) * (c1 + 1)),
+                 o_home = a.add(sizeof(int32_t) * c1), o_cnt = a.add(sizeof(int32_t) * (c1 + 1)), o_sr = a.add(sizeof(int32_t) * 4 * c1);
+    char *base = nullptr;
+    PMK_HIP(hipMalloc((void **)&base, a.bytes));
+    q->d_xq = reinterpret_cast<double *>(base + o_xq);                 // o_xq == 0
+    q->d_stage_t = reinterpret_cast<double *>(base + o_st);
+    q->d_yq = reinterpret_cast<double *>(base + o_yq);
+    q->d_vq = reinterpret_cast<double *>(base + o_vq);
+    q->d_qoff = reinterpret_cast<int64_t *>(base + o_qoff);
+    q->d_home = reinterpret_cast<int32_t *>(base + o_home);
+    q->d_cnt = reinterpret_cast<int32_t *>(base + o_cnt);
+    q->d_stage_r = reinterpret_cast<int32_t *>(base + o_sr);
+    q->nq_cap = (int64_t)cap;
     return 0;
 }
 
@@ -1073,25 +1083,30 @@ int query_set_items(pmk_query *q, int64_t n, const double *xq, const int32_t *re
     return 0;
 }
 
-// per-item buffers, grow only: repeated plans of one query batch reuse them
+// per-item buffers, grow only: repeated plans of one query batch reuse them.  ONE allocation; d_item_t is its base.
 int grow_item_buffers(pmk_query *q, int64_t total)
 {
     if (total <= q->item_cap) return 0;
-    dev_free(q->d_item_region); dev_free(q->d_item_t); dev_free(q->d_item_query);
-    dev_free(q->d_sorted_item); dev_free(q->d_item_pos); dev_free(q->d_u); dev_free(q->d_v); dev_free(q->d_w);
+    dev_free(q->d_item_t);
+    q->d_item_region = nullptr; q->d_item_query = nullptr; q->d_sorted_item = nullptr; q->d_item_pos = nullptr;
+    q->d_u = nullptr; q->d_v = nullptr; q->d_w = nullptr;
     q->item_cap = 0;
-    const int64_t cap = total + total / 8 + 1024;
-    int rc = 0;
-    rc |= dev_alloc(&q->d_item_region, cap);
-    rc |= dev_alloc(&q->d_item_t, cap);
-    rc |= dev_alloc(&q->d_item_query, cap);
-    rc |= dev_alloc(&q->d_sorted_item, cap);
-    rc |= dev_alloc(&q->d_item_pos, cap);
-    rc |= dev_alloc(&q->d_u, cap);
-    rc |= dev_alloc(&q->d_v, cap);
-    rc |= dev_alloc(&q->d_w, cap);
-    if (rc) return -100;
-    q->item_cap = cap;
+    const size_t cap = (size_t)(total + total / 8 + 1024);
+    ArenaLayout a;
+    const size_t o_t = a.add(sizeof(double) * cap), o_u = a.add(sizeof(double) * cap), o_v = a.add(sizeof(double) * cap),
+                 o_w = a.add(sizeof(double) * cap), o_r = a.add(sizeof(int32_t) * cap), o_q = a.add(sizeof(int32_t) * cap),
+                 o_s = a.add(sizeof(int32_t) * cap), o_p = a.add(sizeof(int32_t) * cap);
+    char *base = nullptr;
+    PMK_HIP(hipMalloc((void **)&base, a.bytes));
+    q->d_item_t = reinterpret_cast<double *>(base + o_t);              // o_t == 0
+    q->d_u = reinterpret_cast<double *>(base + o_u);
+    q->d_v = reinterpret_cast<double *>(base + o_v);
+    q->d_w = reinterpret_cast<double *>(base + o_w);
+    q->d_item_region = reinterpret_cast<int32_t *>(base + o_r);
+    q->d_item_query = reinterpret_cast<int32_t *>(base + o_q);
+    q->d_sorted_item = reinterpret_cast<int32_t *>(base + o_s);
+    q->d_item_pos = reinterpret_cast<int32_t *>(base + o_p);
+    q->item_cap = (int64_t)cap;
     return 0;
 }
 
